@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE ONLY — generate tests/golden/ from the REAL reference.
+
+Runs in the build container only (needs oracle/_ref/, i.e. /root/reference compiled by oracle/Makefile).
+Inputs are NOT stored: every case is regenerated from sctl_amd.rand48 (bit-exact drand48, the generator the
+reference's own driver uses, fmm-wrapper.txx:41-55) from the seed in the manifest.  Stored: the reference's
+outputs (GenericKernel::Eval / KernelMatrix / ParticleFMM::EvalDirect on AVX-512), and for some f64 cases the
+reference's long-double evaluation as a truth value.
+
+    python oracle/gen_golden.py            # rewrites tests/golden/*.npz and tests/golden/manifest.json
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import oracle  # noqa: E402
+from sctl_amd.rand48 import Rand48, point_cloud  # noqa: E402
+
+SIZES = [(1, 1), (7, 5), (64, 64), (257, 1000), (1024, 1024)]
+HELMHOLTZ_K = [7.5, 0.3]
+
+
+def ctx_for(name):
+    return np.array(HELMHOLTZ_K) if name.startswith("Helmholtz") else None
+
+
+def main():
+    R = oracle.reference()
+    assert R is not None, "build oracle/_ref first (make -C oracle ref)"
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(out_dir, exist_ok=True)
+    manifest = {"generator": "oracle/gen_golden.py", "reference_isa": R.isa, "helmholtz_k": HELMHOLTZ_K, "cases": []}
+    seed = 100
+    for name in oracle.KERNELS:
+        inf = R.info(name)
+        ctx = ctx_for(name)
+        arrays = {}
+
+        def add(kind, key, arr, **meta):
+            arrays[key] = arr
+            manifest["cases"].append(dict(kernel=name, kind=kind, key=key, **meta))
+
+        for dt in (np.float64, np.float32):
+            tag = "f64" if dt == np.float64 else "f32"
+            for (Nt, Ns) in SIZES:
+                if dt == np.float32 and Nt == 1024:
+                    continue
+                seed += 1
+                xt, xs, xn, f = point_cloud(seed, Nt, Ns, inf["k0"], inf["nd"], dt)
+                u = R.eval(name, xt, xs, xn, f, ctx=ctx, digits=-1)
+                add("eval", "%s_%dx%d" % (tag, Nt, Ns), u, dtype=tag, Nt=Nt, Ns=Ns, seed=seed, digits=-1)
+                if dt == np.float64 and (Nt, Ns) == (257, 1000) and ctx is None:
+                    ld = R.eval(name, *[a.astype(np.longdouble) for a in (xt, xs, xn, f)], digits=-1)
+                    add("truth", "f64_%dx%d_truth" % (Nt, Ns), ld.astype(np.float64), dtype="f64", Nt=Nt, Ns=Ns, seed=seed, digits=-1)
+        # reduced accuracy requests (the reference's approximate rsqrt with fewer Newton steps)
+        for digits in (3, 10):
+            seed += 1
+            xt, xs, xn, f = point_cloud(seed, 257, 1000, inf["k0"], inf["nd"], np.float64)
+            u = R.eval(name, xt, xs, xn, f, ctx=ctx, digits=digits)
+            add("eval", "f64_257x1000_d%d" % digits, u, dtype="f64", Nt=257, Ns=1000, seed=seed, digits=digits)
+        # coincident targets and sources: the r == 0 pair contributes exactly 0 (kernel_functions.hpp:28)
+        for dt, tag in ((np.float64, "f64"), (np.float32, "f32")):
+            seed += 1
+            xt, xs, xn, f = point_cloud(seed, 300, 300, inf["k0"], inf["nd"], dt)
+            u = R.eval(name, xs, xs, xn, f, ctx=ctx, digits=-1)
+            add("eval_self", "%s_self300" % tag, u, dtype=tag, Nt=300, Ns=300, seed=seed, digits=-1)
+        # pre-filled output of the right size is accumulated into (generic-kernel.txx:98-101,184)
+        seed += 1
+        xt, xs, xn, f = point_cloud(seed, 64, 64, inf["k0"], inf["nd"], np.float64)
+        u0 = Rand48(seed + 10000).drand48(64 * inf["k1"]) - 0.5
+        u = R.eval(name, xt, xs, xn, f, v_trg=u0.copy(), ctx=ctx, digits=-1)
+        add("eval_accumulate", "f64_acc64", u, dtype="f64", Nt=64, Ns=64, seed=seed, digits=-1, prefill_seed=seed + 10000)
+        # dense operator (generic-kernel.txx:191-307)
+        seed += 1
+        xt, xs, xn, f = point_cloud(seed, 33, 20, inf["k0"], inf["nd"], np.float64)
+        M = R.kernel_matrix(name, xt, xs, xn, ctx=ctx)
+        add("matrix", "f64_matrix33x20", M, dtype="f64", Nt=33, Ns=20, seed=seed, digits=-1)
+        # ParticleFMM::EvalDirect, one source type and one target type, accuracy 10 as in fmm-wrapper.txx:58
+        if ctx is None:
+            seed += 1
+            xt, xs, xn, f = point_cloud(seed, 500, 500, inf["k0"], inf["nd"], np.float64)
+            u = R.particle_fmm_eval_direct(name, xt, xs, xn, f, digits=10)
+            add("particle_fmm", "f64_fmm500", u, dtype="f64", Nt=500, Ns=500, seed=seed, digits=10)
+        np.savez_compressed(os.path.join(out_dir, name + ".npz"), **arrays)
+        print(name, "cases:", len(arrays))
+    with open(os.path.join(out_dir, "manifest.json"), "w") as fh:
+        json.dump(manifest, fh, indent=1)
+    tot = sum(os.path.getsize(os.path.join(out_dir, f)) for f in os.listdir(out_dir))
+    print("tests/golden: %d files, %.1f KB" % (len(os.listdir(out_dir)), tot / 1024))
+
+
+if __name__ == "__main__":
+    main()
