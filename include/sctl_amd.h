@@ -1,0 +1,124 @@
+/* sctl_amd.h — C ABI of the MI355X (gfx950) direct kernel-summation library, libsctl_amd.so.
+ *
+ * Drop-in boundary for ONE hot path of SCTL (reference snapshot iostanin1/SCTL @ 2024-11-08; file:line
+ * citations are relative to that tree): the all-pairs source->target kernel summation
+ *
+ *     v_trg[t,k1] += scale * sum_s sum_k0 U(x_t - x_s, n_s)[k0][k1] * v_src[s,k0]
+ *
+ * that the reference performs in GenericKernel<uKernel>::Eval (include/sctl/generic-kernel.txx:76-189),
+ * reached from ParticleFMM::EvalDirect (include/sctl/fmm-wrapper.txx:557) and
+ * BoundaryIntegralOp::ComputeFarField (include/sctl/boundary_integral.txx:1063,1073), plus the dense
+ * operator build GenericKernel::KernelMatrix (generic-kernel.txx:191-307).
+ *
+ * Only PODs cross this boundary: plain pointers, sizes, enums.  No C++ types, no torch types.
+ * All arrays are contiguous AoS exactly as SCTL's Vector<Real> holds them (generic-kernel.txx:127-129):
+ *     r_trg[Nt*3], r_src[Ns*3], n_src[Ns*NormalDim] (NULL when NormalDim == 0), v_src[Ns*SrcDim],
+ *     v_trg[Nt*TrgDim].
+ * Every function returns SCTL_AMD_OK (0) or a negative error code; sctl_amd_last_error() gives the text
+ * for the calling thread.  The reference's convention (SCTL_ASSERT -> abort, common.hpp:59-70) is restored
+ * by the header-only C++ wrapper include/sctl_amd/generic-kernel.hpp, not here.
+ * Thread safety: every entry point is re-entrant (KernelMatrix is called from inside an OpenMP parallel
+ * region by boundary_integral.txx:949-986); there is no global mutable state beyond per-thread error text.
+ * There is NO CPU fallback: without a HIP device every compute entry returns SCTL_AMD_ERR_NO_DEVICE.
+ */
+#ifndef SCTL_AMD_H_
+#define SCTL_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCTL_AMD_VERSION 100 /* 0.1.0 */
+
+/* Precision of every array in a call (the reference's template parameter Real). */
+enum sctl_amd_real { SCTL_AMD_F64 = 0, SCTL_AMD_F32 = 1 };
+
+/* Kernel identities.  0-7 replace the functors of include/sctl/kernel_functions.hpp:15-198 (same Name()
+ * strings, scale factors and FLOPS()); 8 and 9 are functors the reference does not have. */
+enum sctl_amd_kernel {
+  SCTL_AMD_LAPLACE3D_FXU = 0,    /* "Laplace3D-FxU"    1x1, 1/(4 pi) / r                        kernel_functions.hpp:15-31   */
+  SCTL_AMD_LAPLACE3D_DXU = 1,    /* "Laplace3D-DxU"    1x1, normal, (r.n) / r^3                 kernel_functions.hpp:33-51   */
+  SCTL_AMD_LAPLACE3D_FXDU = 2,   /* "Laplace3D-FxdU"   1x3, -1/(4 pi) r_j / r^3                 kernel_functions.hpp:53-72   */
+  SCTL_AMD_STOKES3D_FXU = 3,     /* "Stokes3D-FxU"     3x3, Stokeslet, 1/(8 pi)                 kernel_functions.hpp:74-95   */
+  SCTL_AMD_STOKES3D_DXU = 4,     /* "Stokes3D-DxU"     3x3, normal, stresslet, 3/(4 pi)         kernel_functions.hpp:97-120  */
+  SCTL_AMD_STOKES3D_FXT = 5,     /* "Stokes3D-FxT"     3x9, traction tensor, -3/(4 pi)          kernel_functions.hpp:122-146 */
+  SCTL_AMD_STOKES3D_FSXU = 6,    /* "Stokes3D-FSxU"    4x3, Stokeslet + source/sink             kernel_functions.hpp:148-172 */
+  SCTL_AMD_STOKES3D_FXUP = 7,    /* "Stokes3D-FxUP"    3x4, velocity + pressure                 kernel_functions.hpp:174-198 */
+  SCTL_AMD_LAPLACE3D_FDXUDU = 8, /* "Laplace3D-FDxUdU" 2x4, normal, {q, mu} -> {u, grad u}      (new, BASELINE config 2)     */
+  SCTL_AMD_HELMHOLTZ3D_FXU = 9,  /* "Helmholtz3D-FxU"  2x2, exp(ikr)/(4 pi r), ctx = {Re k, Im k} as 2 doubles (new, config 5) */
+  SCTL_AMD_NUM_KERNELS = 10
+};
+
+enum sctl_amd_status {
+  SCTL_AMD_OK = 0,
+  SCTL_AMD_ERR_UNKNOWN_KERNEL = -1, /* functor not implemented on the device: caller keeps its own CPU path          */
+  SCTL_AMD_ERR_BAD_ARGUMENT = -2,   /* the size checks of generic-kernel.txx:94-97                                     */
+  SCTL_AMD_ERR_NO_DEVICE = -3,      /* no HIP device / bad device index: there is no CPU fallback behind this ABI      */
+  SCTL_AMD_ERR_HIP = -4,            /* a HIP runtime call failed; text in sctl_amd_last_error()                        */
+  SCTL_AMD_ERR_BAD_CONTEXT = -5     /* kernel needs a context blob (Helmholtz wavenumber) of another size              */
+};
+
+/* ---- library / registry -------------------------------------------------------------------------------- */
+int sctl_amd_version(void);
+const char* sctl_amd_last_error(void);          /* message of the last failure on the calling thread ("" if none) */
+int sctl_amd_device_count(void);                /* number of HIP devices visible, 0 if none (never an error)       */
+
+/* Kernel id for a functor's Name() string (kernel_functions.hpp:16-19), or SCTL_AMD_ERR_UNKNOWN_KERNEL:
+ * the "is this kernel supported on the device" query of the header wrapper. */
+int sctl_amd_kernel_id(const char* name);
+const char* sctl_amd_kernel_name(int kernel);   /* NULL for an unknown id */
+/* Shape table: SrcDim, TrgDim, NormalDim (generic-kernel.hpp:59-84), FLOPS() (kernel_functions.hpp:20-22),
+ * uKerScaleFactor<double>() (:23-25) and the size in bytes of the context blob the kernel needs (0 = none).
+ * Any output pointer may be NULL. */
+int sctl_amd_kernel_info(int kernel, int* src_dim, int* trg_dim, int* normal_dim, int* flops, double* scale, int* ctx_bytes);
+/* Algorithmic flops per pair interaction by SURVEY.md §8(d): 3 + FLOPS() + 2*SrcDim*TrgDim. */
+int sctl_amd_flops_per_pair(int kernel);
+
+/* ---- the hot path: GenericKernel::Eval ------------------------------------------------------------------- */
+/* Device-resident form.  All five arrays are DEVICE pointers on the current HIP device; `stream` is a
+ * hipStream_t (NULL = default stream); the call only enqueues work on that stream and returns.
+ * v_trg must already hold Nt*TrgDim values and is ACCUMULATED into (generic-kernel.txx:182-186);
+ * resizing-and-zeroing (generic-kernel.txx:98-101) is the host wrapper's job.
+ * digits: requested decimal digits, -1 = full precision of `real` (generic-kernel.txx:46-74,77).
+ * ctx/ctx_bytes: HOST pointer to the kernel's context blob, copied at launch (replaces the unsized
+ * ctx_ptr of generic-kernel.hpp:90,150); NULL/0 for kernels without one. */
+int sctl_amd_eval_device(int kernel, int real, int64_t Nt, int64_t Ns, const void* r_trg, const void* r_src, const void* n_src,
+                         const void* v_src, void* v_trg, int digits, const void* ctx, int ctx_bytes, void* stream);
+
+/* Host-buffer form: the drop-in for GenericKernel<uKer>::Eval<Real,enable_openmp,digits>
+ * (generic-kernel.hpp:123) and for the type-erased static entry ParticleFMM stores
+ * (generic-kernel.hpp:110, fmm-wrapper.txx:152-153).  All arrays are HOST pointers; the call uploads,
+ * evaluates on `device`, downloads and accumulates into v_trg, and returns when v_trg is final. */
+int sctl_amd_eval_host(int kernel, int real, int64_t Nt, int64_t Ns, const void* r_trg, const void* r_src, const void* n_src,
+                       const void* v_src, void* v_trg, int digits, const void* ctx, int ctx_bytes, int device);
+
+/* Host-buffer form over several GPUs of one node from ONE process: targets are block-partitioned,
+ * GPU g of G gets [Nt*g/G, Nt*(g+1)/G) — the rank partition formula of fmm-wrapper.txx:507 — and sources are
+ * replicated.  devices == NULL means devices 0..n_devices-1. */
+int sctl_amd_eval_host_multi(int kernel, int real, int64_t Nt, int64_t Ns, const void* r_trg, const void* r_src, const void* n_src,
+                             const void* v_src, void* v_trg, int digits, const void* ctx, int ctx_bytes, const int* devices,
+                             int n_devices);
+
+/* ---- GenericKernel::KernelMatrix (generic-kernel.txx:191-307) ---------------------------------------------- */
+/* M is (Ns*SrcDim) x (Nt*TrgDim), row-major, OVERWRITTEN, scale factor included. */
+int sctl_amd_kernel_matrix_device(int kernel, int real, int64_t Nt, int64_t Ns, const void* r_trg, const void* r_src,
+                                  const void* n_src, void* M, int digits, const void* ctx, int ctx_bytes, void* stream);
+int sctl_amd_kernel_matrix_host(int kernel, int real, int64_t Nt, int64_t Ns, const void* r_trg, const void* r_src,
+                                const void* n_src, void* M, int digits, const void* ctx, int ctx_bytes, int device);
+
+/* ---- accounting (the reference's Profile::IncrementCounter(FLOP, Ns*Nt*FLOPS()), generic-kernel.txx:188) ---- */
+/* Process-wide counters, updated atomically by every eval / kernel_matrix call. */
+void sctl_amd_counters(int64_t* pair_interactions, int64_t* sctl_flops);
+void sctl_amd_reset_counters(void);
+
+/* Launch geometry chosen for a problem (for benchmarks and DESIGN.md; no side effects):
+ * targets per lane, source splits, workgroups, and bytes of the partial-sum workspace. */
+int sctl_amd_eval_plan(int kernel, int real, int64_t Nt, int64_t Ns, int digits, int* trg_per_lane, int* src_splits,
+                       int64_t* workgroups, int64_t* workspace_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCTL_AMD_H_ */

@@ -1,0 +1,119 @@
+// GenericKernel<uKernel>: the kernel-object surface of the reference (include/sctl/generic-kernel.hpp:31-152) with
+// the evaluation routed to the MI355X library instead of the reference's OpenMP + Vec<> loop nest.
+//
+// Same member names, argument order and semantics as the reference:
+//   CoordDim / NormalDim / SrcDim / TrgDim            generic-kernel.hpp:59-84
+//   SetCtxPtr / GetCtxPtr                             generic-kernel.hpp:90,96
+//   Eval<Real, enable_openmp, digits>(v_trg, r_trg, r_src, n_src, v_src) const           generic-kernel.hpp:123
+//   static Eval<Real, enable_openmp>(..., Integer digits, ConstIterator<char> self)      generic-kernel.hpp:110
+//   KernelMatrix<Real, enable_openmp, digits>(M, Xt, Xs, Xn) const                       generic-kernel.hpp:135
+// Behaviour kept: size checks abort (generic-kernel.txx:94-97); a v_trg of the wrong size is resized and zeroed,
+// one of the right size is ACCUMULATED into (generic-kernel.txx:98-101,182-186); M is resized if needed and
+// overwritten (generic-kernel.txx:199-202); FLOP accounting (generic-kernel.txx:188) lives in sctl_amd_counters().
+// `enable_openmp` is accepted for source compatibility and ignored: parallelism is the GPU's.
+//
+// What differs, by necessity: a micro-kernel here is a descriptor (Name, FLOPS, scale factor, dimensions, context
+// size) of a kernel implemented in HIP inside libsctl_amd.so, not host arithmetic.  A functor whose Name() the
+// library does not know cannot run on the device; Eval then aborts with a clear message — there is deliberately NO
+// host fallback in this header (use IsSupported() to keep such functors on the caller's own CPU path).
+#ifndef SCTL_AMD_GENERIC_KERNEL_HPP_
+#define SCTL_AMD_GENERIC_KERNEL_HPP_
+
+#include <string>
+
+#include "common.hpp"
+#include "matrix.hpp"
+#include "vector.hpp"
+
+namespace sctl_amd {
+
+template <class uKernel> class GenericKernel : public uKernel {
+  static constexpr Integer DIM = 3;
+  static constexpr Integer KDIM0 = uKernel::SRC_DIM;
+  static constexpr Integer KDIM1 = uKernel::TRG_DIM;
+  static constexpr Integer N_DIM = uKernel::NORMAL_DIM;
+
+ public:
+  GenericKernel() : ctx_ptr(nullptr) {}
+
+  static constexpr Integer CoordDim() { return DIM; }
+  static constexpr Integer NormalDim() { return N_DIM; }
+  static constexpr Integer SrcDim() { return KDIM0; }
+  static constexpr Integer TrgDim() { return KDIM1; }
+
+  // The context is a borrowed host pointer, as in the reference; its size comes from the functor (CTX_BYTES)
+  // because the device needs a sized, copyable blob.
+  void SetCtxPtr(void* ctx) { ctx_ptr = ctx; }
+  const void* GetCtxPtr() const { return ctx_ptr; }
+
+  // Device kernel id of this functor, or a negative value when libsctl_amd.so does not implement it.
+  static int DeviceKernelId() {
+    static const int id = sctl_amd_kernel_id(uKernel::Name().c_str());
+    return id;
+  }
+  static bool IsSupported() { return DeviceKernelId() >= 0; }
+
+  template <class Real, bool enable_openmp>
+  static void Eval(Vector<Real>& v_trg, const Vector<Real>& r_trg, const Vector<Real>& r_src, const Vector<Real>& n_src,
+                   const Vector<Real>& v_src, Integer digits, ConstIterator<char> self) {
+    ((ConstIterator<GenericKernel<uKernel>>)self)->EvalImpl(v_trg, r_trg, r_src, n_src, v_src, digits);
+  }
+
+  template <class Real, bool enable_openmp = false, Integer digits = -1>
+  void Eval(Vector<Real>& v_trg, const Vector<Real>& r_trg, const Vector<Real>& r_src, const Vector<Real>& n_src,
+            const Vector<Real>& v_src) const {
+    EvalImpl(v_trg, r_trg, r_src, n_src, v_src, digits);
+  }
+
+  template <class Real, bool enable_openmp = false, Integer digits = -1>
+  void KernelMatrix(Matrix<Real>& M, const Vector<Real>& Xt, const Vector<Real>& Xs, const Vector<Real>& Xn) const {
+    const Long Ns = Xs.Dim() / DIM;
+    const Long Nt = Xt.Dim() / DIM;
+    SCTL_AMD_ASSERT(Xt.Dim() == Nt * DIM);
+    SCTL_AMD_ASSERT(Xs.Dim() == Ns * DIM);
+    SCTL_AMD_ASSERT(Xn.Dim() == Ns * N_DIM || !N_DIM);
+    if (M.Dim(0) != Ns * KDIM0 || M.Dim(1) != Nt * KDIM1) {
+      M.ReInit(Ns * KDIM0, Nt * KDIM1);
+      M.SetZero();
+    }
+    RequireSupported();
+    const int rc = sctl_amd_kernel_matrix_host(DeviceKernelId(), RealTag<Real>::value, Nt, Ns, Xt.begin(), Xs.begin(),
+                                               N_DIM ? Xn.begin() : nullptr, M.begin(), (int)digits, ctx_ptr, (int)uKernel::CTX_BYTES,
+                                               DeviceSet::Get()[0]);
+    CheckStatus(rc, "sctl_amd_kernel_matrix_host");
+  }
+
+ private:
+  static void RequireSupported() {
+    if (!IsSupported()) {
+      const std::string msg = "kernel '" + uKernel::Name() + "' is not implemented in libsctl_amd.so (no host fallback in sctl_amd)";
+      SCTL_AMD_ERROR(msg.c_str());
+    }
+  }
+
+  template <class Real>
+  void EvalImpl(Vector<Real>& v_trg, const Vector<Real>& r_trg, const Vector<Real>& r_src, const Vector<Real>& n_src,
+                const Vector<Real>& v_src, Integer digits) const {
+    const Long Ns = r_src.Dim() / DIM;
+    const Long Nt = r_trg.Dim() / DIM;
+    SCTL_AMD_ASSERT(r_trg.Dim() == Nt * DIM);
+    SCTL_AMD_ASSERT(r_src.Dim() == Ns * DIM);
+    SCTL_AMD_ASSERT(v_src.Dim() == Ns * KDIM0);
+    SCTL_AMD_ASSERT(n_src.Dim() == Ns * N_DIM || !N_DIM);
+    if (v_trg.Dim() != Nt * KDIM1) {
+      v_trg.ReInit(Nt * KDIM1);
+      v_trg.SetZero();
+    }
+    RequireSupported();
+    const std::vector<int>& devs = DeviceSet::Get();
+    const int rc = sctl_amd_eval_host_multi(DeviceKernelId(), RealTag<Real>::value, Nt, Ns, r_trg.begin(), r_src.begin(),
+                                            N_DIM ? n_src.begin() : nullptr, v_src.begin(), v_trg.begin(), (int)digits, ctx_ptr,
+                                            (int)uKernel::CTX_BYTES, devs.data(), (int)devs.size());
+    CheckStatus(rc, "sctl_amd_eval_host_multi");
+  }
+
+  void* ctx_ptr;
+};
+
+}  // namespace sctl_amd
+#endif  // SCTL_AMD_GENERIC_KERNEL_HPP_

@@ -1,0 +1,266 @@
+"""ctypes binding of include/sctl_amd.h and a GenericKernel mirror of the reference's kernel objects.
+
+Names, argument order and semantics follow the reference (file:line relative to /root/reference):
+  GenericKernel.Eval(v_trg, r_trg, r_src, n_src, v_src)   include/sctl/generic-kernel.hpp:123, generic-kernel.txx:76-189
+  GenericKernel.KernelMatrix(M, Xt, Xs, Xn)               include/sctl/generic-kernel.hpp:135, generic-kernel.txx:191-307
+  SrcDim / TrgDim / NormalDim / CoordDim / Name / FLOPS   include/sctl/generic-kernel.hpp:59-84, kernel_functions.hpp:16-22
+numpy arrays go through the host-buffer entry points, torch CUDA tensors through the device-resident ones
+(on torch's current stream).  A missing or failing library raises; nothing is computed on the CPU here.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+F64, F32 = 0, 1
+KERNEL_NAMES = ["Laplace3D-FxU", "Laplace3D-DxU", "Laplace3D-FxdU", "Stokes3D-FxU", "Stokes3D-DxU", "Stokes3D-FxT", "Stokes3D-FSxU",
+                "Stokes3D-FxUP", "Laplace3D-FDxUdU", "Helmholtz3D-FxU"]
+
+# every symbol include/sctl_amd.h declares (tests/test_boundary.py checks the header against this list and the .so)
+SYMBOLS = ["sctl_amd_version", "sctl_amd_last_error", "sctl_amd_device_count", "sctl_amd_kernel_id", "sctl_amd_kernel_name",
+           "sctl_amd_kernel_info", "sctl_amd_flops_per_pair", "sctl_amd_eval_device", "sctl_amd_eval_host", "sctl_amd_eval_host_multi",
+           "sctl_amd_kernel_matrix_device", "sctl_amd_kernel_matrix_host", "sctl_amd_counters", "sctl_amd_reset_counters",
+           "sctl_amd_eval_plan"]
+
+
+class SctlAmdError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(_HERE, "libsctl_amd.so")
+
+
+def lib():
+    """The loaded C-ABI library.  Raises if it has not been built: there is no fallback."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise SctlAmdError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
+                           "`make -C sctl_amd/csrc` (hipcc, gfx950); sctl_amd has no CPU fallback" % path)
+    L = C.CDLL(path)
+    vp, i64, ci = C.c_void_p, C.c_int64, C.c_int
+    L.sctl_amd_last_error.restype = C.c_char_p
+    L.sctl_amd_kernel_name.restype = C.c_char_p
+    L.sctl_amd_kernel_id.argtypes = [C.c_char_p]
+    L.sctl_amd_kernel_info.argtypes = [ci] + [C.POINTER(C.c_int)] * 4 + [C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    L.sctl_amd_eval_device.argtypes = [ci, ci, i64, i64, vp, vp, vp, vp, vp, ci, vp, ci, vp]
+    L.sctl_amd_eval_host.argtypes = [ci, ci, i64, i64, vp, vp, vp, vp, vp, ci, vp, ci, ci]
+    L.sctl_amd_eval_host_multi.argtypes = [ci, ci, i64, i64, vp, vp, vp, vp, vp, ci, vp, ci, C.POINTER(C.c_int), ci]
+    L.sctl_amd_kernel_matrix_device.argtypes = [ci, ci, i64, i64, vp, vp, vp, vp, ci, vp, ci, vp]
+    L.sctl_amd_kernel_matrix_host.argtypes = [ci, ci, i64, i64, vp, vp, vp, vp, ci, vp, ci, ci]
+    L.sctl_amd_counters.argtypes = [C.POINTER(i64), C.POINTER(i64)]
+    L.sctl_amd_counters.restype = None
+    L.sctl_amd_reset_counters.restype = None
+    L.sctl_amd_eval_plan.argtypes = [ci, ci, i64, i64, ci, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(i64), C.POINTER(i64)]
+    _LIB = L
+    return L
+
+
+def last_error():
+    return lib().sctl_amd_last_error().decode()
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise SctlAmdError("%s failed with status %d: %s" % (what, rc, last_error()))
+
+
+def device_count():
+    return lib().sctl_amd_device_count()
+
+
+def kernel_id(name):
+    """Device kernel id for a functor Name(), or raises KeyError (the 'is it supported' query)."""
+    k = name if isinstance(name, int) else lib().sctl_amd_kernel_id(name.encode())
+    if k < 0 or k >= len(KERNEL_NAMES):
+        raise KeyError("kernel %r is not implemented on the device" % (name,))
+    return k
+
+
+def kernel_info(name):
+    k = kernel_id(name)
+    v = [C.c_int() for _ in range(4)]
+    sc, cb = C.c_double(), C.c_int()
+    _check(lib().sctl_amd_kernel_info(k, C.byref(v[0]), C.byref(v[1]), C.byref(v[2]), C.byref(v[3]), C.byref(sc), C.byref(cb)), "kernel_info")
+    return dict(id=k, name=lib().sctl_amd_kernel_name(k).decode(), k0=v[0].value, k1=v[1].value, nd=v[2].value, flops=v[3].value,
+                scale=sc.value, ctx_bytes=cb.value)
+
+
+def flops_per_pair(name):
+    return lib().sctl_amd_flops_per_pair(kernel_id(name))
+
+
+def plan(name, real, Nt, Ns, digits=-1):
+    t, s = C.c_int(), C.c_int()
+    wg, ws = C.c_int64(), C.c_int64()
+    _check(lib().sctl_amd_eval_plan(kernel_id(name), real, Nt, Ns, digits, C.byref(t), C.byref(s), C.byref(wg), C.byref(ws)), "eval_plan")
+    return dict(trg_per_lane=t.value, src_splits=s.value, workgroups=wg.value, workspace_bytes=ws.value)
+
+
+def counters():
+    p, f = C.c_int64(), C.c_int64()
+    lib().sctl_amd_counters(C.byref(p), C.byref(f))
+    return dict(pair_interactions=p.value, sctl_flops=f.value)
+
+
+def reset_counters():
+    lib().sctl_amd_reset_counters()
+
+
+def _ctx_blob(info, ctx):
+    if info["ctx_bytes"] == 0:
+        return None, None, 0
+    if ctx is None:
+        raise SctlAmdError("%s needs a context of %d bytes (e.g. the complex wavenumber)" % (info["name"], info["ctx_bytes"]))
+    buf = np.ascontiguousarray(ctx, dtype=np.float64)
+    return buf, buf.ctypes.data_as(C.c_void_p), buf.nbytes
+
+
+def _real_of(dtype):
+    dt = np.dtype(dtype)
+    if dt == np.float64:
+        return F64
+    if dt == np.float32:
+        return F32
+    raise SctlAmdError("only float64 and float32 are supported, got %s" % dt)
+
+
+def _np_ptr(a, dt, n, what):
+    if n == 0:
+        return None
+    if a is None or a.dtype != dt or a.size != n or not a.flags["C_CONTIGUOUS"]:
+        raise SctlAmdError("%s must be a contiguous %s array of %d values" % (what, np.dtype(dt).name, n))
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def eval_host(name, r_trg, r_src, n_src, v_src, v_trg=None, digits=-1, ctx=None, device=0, devices=None):
+    """GenericKernel::Eval on host (numpy) arrays.  v_trg of the right size is ACCUMULATED into
+    (generic-kernel.txx:184); any other size (or None) gives a fresh zeroed result (generic-kernel.txx:98-101)."""
+    info = kernel_info(name)
+    dt = r_trg.dtype
+    real = _real_of(dt)
+    Nt, Ns = r_trg.size // 3, r_src.size // 3
+    if r_trg.size != Nt * 3 or r_src.size != Ns * 3:
+        raise SctlAmdError("coordinate arrays must hold 3 values per point")
+    if v_trg is None or v_trg.size != Nt * info["k1"]:
+        v_trg = np.zeros(Nt * info["k1"], dtype=dt)
+    keep, cp, cb = _ctx_blob(info, ctx)
+    args = [info["id"], real, Nt, Ns, _np_ptr(r_trg, dt, Nt * 3, "r_trg"), _np_ptr(r_src, dt, Ns * 3, "r_src"),
+            _np_ptr(n_src, dt, Ns * info["nd"], "n_src"), _np_ptr(v_src, dt, Ns * info["k0"], "v_src"),
+            _np_ptr(v_trg, dt, Nt * info["k1"], "v_trg"), digits, cp, cb]
+    if devices is None:
+        _check(lib().sctl_amd_eval_host(*args, device), "eval_host")
+    else:
+        devs = (C.c_int * len(devices))(*devices)
+        _check(lib().sctl_amd_eval_host_multi(*args, devs, len(devices)), "eval_host_multi")
+    return v_trg
+
+
+def _t_ptr(t, torch_dtype, n, what):
+    if n == 0:
+        return None
+    if t is None or t.dtype != torch_dtype or t.numel() != n or not t.is_contiguous() or not t.is_cuda:
+        raise SctlAmdError("%s must be a contiguous CUDA tensor of %d %s values" % (what, n, torch_dtype))
+    return C.c_void_p(t.data_ptr())
+
+
+def eval_device(name, r_trg, r_src, n_src, v_src, v_trg=None, digits=-1, ctx=None, stream=None):
+    """GenericKernel::Eval on torch CUDA tensors, enqueued on `stream` (default: torch's current stream)."""
+    import torch
+    info = kernel_info(name)
+    tdt = r_trg.dtype
+    real = F64 if tdt == torch.float64 else _real_of(np.float32 if tdt == torch.float32 else np.int8)
+    Nt, Ns = r_trg.numel() // 3, r_src.numel() // 3
+    if v_trg is None or v_trg.numel() != Nt * info["k1"]:
+        v_trg = torch.zeros(Nt * info["k1"], dtype=tdt, device=r_trg.device)
+    keep, cp, cb = _ctx_blob(info, ctx)
+    with torch.cuda.device(r_trg.device):
+        st = stream if stream is not None else torch.cuda.current_stream()
+        _check(lib().sctl_amd_eval_device(info["id"], real, Nt, Ns, _t_ptr(r_trg, tdt, Nt * 3, "r_trg"), _t_ptr(r_src, tdt, Ns * 3, "r_src"),
+                                          _t_ptr(n_src, tdt, Ns * info["nd"], "n_src"), _t_ptr(v_src, tdt, Ns * info["k0"], "v_src"),
+                                          _t_ptr(v_trg, tdt, Nt * info["k1"], "v_trg"), digits, cp, cb, C.c_void_p(st.cuda_stream)),
+               "eval_device")
+    return v_trg
+
+
+def kernel_matrix_host(name, r_trg, r_src, n_src, digits=-1, ctx=None, device=0):
+    """GenericKernel::KernelMatrix on numpy arrays: returns M of shape (Ns*SrcDim, Nt*TrgDim), scale included."""
+    info = kernel_info(name)
+    dt = r_trg.dtype
+    real = _real_of(dt)
+    Nt, Ns = r_trg.size // 3, r_src.size // 3
+    M = np.zeros((Ns * info["k0"], Nt * info["k1"]), dtype=dt)
+    keep, cp, cb = _ctx_blob(info, ctx)
+    _check(lib().sctl_amd_kernel_matrix_host(info["id"], real, Nt, Ns, _np_ptr(r_trg, dt, Nt * 3, "r_trg"), _np_ptr(r_src, dt, Ns * 3, "r_src"),
+                                             _np_ptr(n_src, dt, Ns * info["nd"], "n_src"), _np_ptr(M, dt, M.size, "M"), digits, cp, cb, device),
+           "kernel_matrix_host")
+    return M
+
+
+def kernel_matrix_device(name, r_trg, r_src, n_src, M=None, digits=-1, ctx=None, stream=None):
+    import torch
+    info = kernel_info(name)
+    tdt = r_trg.dtype
+    real = F64 if tdt == torch.float64 else F32
+    Nt, Ns = r_trg.numel() // 3, r_src.numel() // 3
+    if M is None or M.numel() != Ns * info["k0"] * Nt * info["k1"]:
+        M = torch.empty((Ns * info["k0"], Nt * info["k1"]), dtype=tdt, device=r_trg.device)
+    keep, cp, cb = _ctx_blob(info, ctx)
+    with torch.cuda.device(r_trg.device):
+        st = stream if stream is not None else torch.cuda.current_stream()
+        _check(lib().sctl_amd_kernel_matrix_device(info["id"], real, Nt, Ns, _t_ptr(r_trg, tdt, Nt * 3, "r_trg"),
+                                                   _t_ptr(r_src, tdt, Ns * 3, "r_src"), _t_ptr(n_src, tdt, Ns * info["nd"], "n_src"),
+                                                   _t_ptr(M, tdt, M.numel(), "M"), digits, cp, cb, C.c_void_p(st.cuda_stream)),
+               "kernel_matrix_device")
+    return M
+
+
+class GenericKernel:
+    """Python mirror of a reference kernel object (GenericKernel<uKernel>, generic-kernel.hpp:31-152)."""
+
+    def __init__(self, name, ctx=None):
+        self._info = kernel_info(name)
+        self._ctx = ctx
+
+    def Name(self):
+        return self._info["name"]
+
+    def FLOPS(self):
+        return self._info["flops"]
+
+    def uKerScaleFactor(self):
+        return self._info["scale"]
+
+    def CoordDim(self):
+        return 3
+
+    def NormalDim(self):
+        return self._info["nd"]
+
+    def SrcDim(self):
+        return self._info["k0"]
+
+    def TrgDim(self):
+        return self._info["k1"]
+
+    def SetCtxPtr(self, ctx):
+        self._ctx = ctx
+
+    def GetCtxPtr(self):
+        return self._ctx
+
+    def Eval(self, v_trg, r_trg, r_src, n_src, v_src, digits=-1, **kw):
+        if isinstance(r_trg, np.ndarray):
+            return eval_host(self._info["id"], r_trg, r_src, n_src, v_src, v_trg, digits, self._ctx, **kw)
+        return eval_device(self._info["id"], r_trg, r_src, n_src, v_src, v_trg, digits, self._ctx, **kw)
+
+    def KernelMatrix(self, M, Xt, Xs, Xn, digits=-1, **kw):
+        if isinstance(Xt, np.ndarray):
+            return kernel_matrix_host(self._info["id"], Xt, Xs, Xn, digits, self._ctx, **kw)
+        return kernel_matrix_device(self._info["id"], Xt, Xs, Xn, M, digits, self._ctx, **kw)

@@ -1,0 +1,375 @@
+// C ABI of libsctl_amd.so (include/sctl_amd.h): argument checks, launch planning, host<->device staging
+// and the one-process multi-GPU driver.  All arithmetic lives in eval_kernel.hpp / ukernels.hpp.
+#include "../../include/sctl_amd.h"
+#include "launch.hpp"
+
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace sctl_amd {
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIP_TRY(expr)                                                                                        \
+  do {                                                                                                       \
+    hipError_t e_ = (expr);                                                                                  \
+    if (e_ != hipSuccess) return fail(SCTL_AMD_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+  } while (0)
+
+const KernelEntry* registry(int id) {
+  static const KernelEntry* tab[SCTL_AMD_NUM_KERNELS] = {
+      &entry_Laplace3D_FxU(),  &entry_Laplace3D_DxU(),  &entry_Laplace3D_FxdU(),   &entry_Stokes3D_FxU(),   &entry_Stokes3D_DxU(),
+      &entry_Stokes3D_FxT(),   &entry_Stokes3D_FSxU(),  &entry_Stokes3D_FxUP(),    &entry_Laplace3D_FDxUdU(), &entry_Helmholtz3D_FxU()};
+  return (id >= 0 && id < SCTL_AMD_NUM_KERNELS) ? tab[id] : nullptr;
+}
+
+std::atomic<int64_t> g_pairs{0}, g_flops{0};
+
+template <class R> EvalLaunch<R> pick_eval(const KernelEntry& k, int mode, int t);
+template <> EvalLaunch<double> pick_eval<double>(const KernelEntry& k, int mode, int t) { return k.eval_f64[mode][t]; }
+template <> EvalLaunch<float> pick_eval<float>(const KernelEntry& k, int mode, int t) { return k.eval_f32[mode][t]; }
+template <class R> MatrixLaunch<R> pick_matrix(const KernelEntry& k, int mode);
+template <> MatrixLaunch<double> pick_matrix<double>(const KernelEntry& k, int mode) { return k.matrix_f64[mode]; }
+template <> MatrixLaunch<float> pick_matrix<float>(const KernelEntry& k, int mode) { return k.matrix_f32[mode]; }
+
+int device_count_quiet() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
+
+int cu_count() {   // CUs of the current device; 256 (MI355X) when planning without a device
+  static std::once_flag once;
+  static int cus = 256;
+  std::call_once(once, [] {
+    int dev = 0, n = 0;
+    if (device_count_quiet() > 0 && hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+      cus = n;
+  });
+  return cus;
+}
+
+// digits -> refinement mode of ukernels.hpp rsqrt_masked (the reference maps digits to Newton iteration
+// counts at compile time, intrin-wrapper.hpp:3025-3050; -1 and >= 16 mean full precision, generic-kernel.txx:46-77)
+int mode_for(int real, int digits) {
+  if (real == SCTL_AMD_F64) {
+    if (digits < 0 || digits > 14) return 2;
+    return digits <= 7 ? 0 : 1;
+  }
+  return (digits < 0 || digits <= 7) ? 0 : 1;
+}
+
+struct Plan {
+  int t_idx;        // index into kTvalues
+  int splits;
+  int64_t chunk;    // sources per split (multiple of kTile)
+  int64_t wg_x;
+  int64_t workspace_bytes;
+};
+
+// Geometry: enough workgroups for >= 4 per CU; prefer 2 targets per lane (halves LDS reads per pair)
+// once there are enough targets, otherwise split the source range (SURVEY.md §8e sizes: 2^14 .. 2^23).
+Plan make_plan(const KernelEntry& k, int real, int64_t Nt, int64_t Ns) {
+  const int64_t want = (int64_t)cu_count() * 4;
+  Plan p{};
+  int t = (k.k1 * (real == SCTL_AMD_F64 ? 2 : 1) > 8) ? 1 : 2;   // big accumulator sets (Stokes3D-FxT fp64): 1 target per lane
+  if ((Nt + kBlock * t - 1) / (kBlock * t) < want) t = 1;
+  p.t_idx = (t == 1) ? 0 : 1;
+  p.wg_x = (Nt + (int64_t)kBlock * t - 1) / ((int64_t)kBlock * t);
+  if (p.wg_x < 1) p.wg_x = 1;
+  const int64_t ntile = (Ns + kTile - 1) / kTile;
+  int64_t s = (want + p.wg_x - 1) / p.wg_x;
+  if (s > ntile) s = ntile;
+  if (s > 1024) s = 1024;
+  if (s < 1) s = 1;
+  int64_t tiles_per = (ntile + s - 1) / s;
+  if (tiles_per < 1) tiles_per = 1;
+  p.chunk = tiles_per * kTile;
+  p.splits = (int)((Ns + p.chunk - 1) / p.chunk);
+  if (p.splits < 1) p.splits = 1;
+  p.workspace_bytes = (p.splits > 1) ? (int64_t)p.splits * Nt * k.k1 * (real == SCTL_AMD_F64 ? 8 : 4) : 0;
+  return p;
+}
+
+int check_common(const KernelEntry* k, int real, int64_t Nt, int64_t Ns, const void* r_trg, const void* r_src, const void* n_src,
+                 int ctx_bytes, const void* ctx) {
+  if (!k) return fail(SCTL_AMD_ERR_UNKNOWN_KERNEL, "unknown kernel id");
+  if (real != SCTL_AMD_F64 && real != SCTL_AMD_F32) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "real must be SCTL_AMD_F64 or SCTL_AMD_F32");
+  if (Nt < 0 || Ns < 0) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "negative size");
+  if ((Nt > 0 && !r_trg) || (Ns > 0 && !r_src)) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "null coordinate array");
+  if (Ns > 0 && k->nd > 0 && !n_src) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, std::string(k->name) + " needs source normals (n_src is null)");
+  if (k->ctx_bytes != 0 && (ctx_bytes != k->ctx_bytes || !ctx))
+    return fail(SCTL_AMD_ERR_BAD_CONTEXT, std::string(k->name) + " needs a context blob of " + std::to_string(k->ctx_bytes) + " bytes");
+  return SCTL_AMD_OK;
+}
+
+KerCtx make_ctx(const KernelEntry& k, const void* ctx) {
+  KerCtx c{};
+  if (k.ctx_bytes > 0) std::memcpy(c.v, ctx, (size_t)k.ctx_bytes);
+  return c;
+}
+
+template <class R>
+int eval_device_t(const KernelEntry& k, int real, int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* xn, const R* f, R* v, int digits,
+                  const void* ctx, hipStream_t st) {
+  if (Nt == 0 || Ns == 0) return SCTL_AMD_OK;   // nothing to add (generic-kernel.txx:153-186 degenerates to v_trg += 0)
+  const Plan p = make_plan(k, real, Nt, Ns);
+  const int mode = mode_for(real, digits);
+  EvalArgs<R> a{};
+  a.Nt = Nt; a.Ns = Ns; a.xt = xt; a.xs = xs; a.xn = xn; a.f = f; a.v_trg = v; a.partial = nullptr;
+  a.chunk = p.chunk; a.scale = (R)k.scale; a.ctx = make_ctx(k, ctx);
+  if (p.splits > 1) {
+    void* ws = nullptr;
+    HIP_TRY(hipMallocAsync(&ws, (size_t)p.workspace_bytes, st));
+    a.partial = (R*)ws;
+  }
+  const dim3 grid((unsigned)p.wg_x, (unsigned)p.splits);
+  pick_eval<R>(k, mode, p.t_idx)(a, grid, st);
+  HIP_TRY(hipGetLastError());
+  if (p.splits > 1) {
+    const int64_t n = Nt * k.k1;
+    hipLaunchKernelGGL((reduce_splits_kernel<R>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, v, (const R*)a.partial, n,
+                       p.splits, (R)k.scale);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipFreeAsync(a.partial, st));
+  }
+  g_pairs += Nt * Ns;
+  g_flops += Nt * Ns * k.flops;
+  return SCTL_AMD_OK;
+}
+
+template <class R>
+int matrix_device_t(const KernelEntry& k, int real, int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* xn, R* M, int digits,
+                    const void* ctx, hipStream_t st) {
+  if (Nt == 0 || Ns == 0) return SCTL_AMD_OK;
+  const int mode = mode_for(real, digits);
+  const dim3 grid((unsigned)((Nt + kBlock - 1) / kBlock), (unsigned)(Ns < 65535 ? Ns : 65535));
+  pick_matrix<R>(k, mode)(Nt, Ns, xt, xs, xn, M, (R)k.scale, make_ctx(k, ctx), grid, st);
+  HIP_TRY(hipGetLastError());
+  g_pairs += Nt * Ns;
+  g_flops += Nt * Ns * k.flops;
+  return SCTL_AMD_OK;
+}
+
+// RAII device buffers for the host-pointer entry points
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t bytes) { return bytes ? hipMalloc(&p, bytes) : hipSuccess; }
+};
+struct StreamGuard {
+  hipStream_t s = nullptr;
+  ~StreamGuard() { if (s) (void)hipStreamDestroy(s); }
+};
+
+// one GPU: targets [t0, t1) of the host arrays, all sources
+int eval_host_slab(const KernelEntry& k, int real, int64_t t0, int64_t t1, int64_t Ns, const void* r_trg, const void* r_src, const void* n_src,
+                   const void* v_src, void* v_trg, int digits, const void* ctx, int device) {
+  const size_t rs = (real == SCTL_AMD_F64) ? 8 : 4;
+  const int64_t Nt = t1 - t0;
+  if (Nt <= 0 || Ns <= 0) return SCTL_AMD_OK;
+  HIP_TRY(hipSetDevice(device));
+  StreamGuard st;
+  HIP_TRY(hipStreamCreateWithFlags(&st.s, hipStreamNonBlocking));
+  DevBuf dxt, dxs, dxn, df, dv;
+  HIP_TRY(dxt.alloc((size_t)Nt * 3 * rs));
+  HIP_TRY(dxs.alloc((size_t)Ns * 3 * rs));
+  HIP_TRY(dxn.alloc((size_t)Ns * k.nd * rs));
+  HIP_TRY(df.alloc((size_t)Ns * k.k0 * rs));
+  HIP_TRY(dv.alloc((size_t)Nt * k.k1 * rs));
+  HIP_TRY(hipMemcpyAsync(dxt.p, (const char*)r_trg + (size_t)t0 * 3 * rs, (size_t)Nt * 3 * rs, hipMemcpyHostToDevice, st.s));
+  HIP_TRY(hipMemcpyAsync(dxs.p, r_src, (size_t)Ns * 3 * rs, hipMemcpyHostToDevice, st.s));
+  if (k.nd) HIP_TRY(hipMemcpyAsync(dxn.p, n_src, (size_t)Ns * k.nd * rs, hipMemcpyHostToDevice, st.s));
+  HIP_TRY(hipMemcpyAsync(df.p, v_src, (size_t)Ns * k.k0 * rs, hipMemcpyHostToDevice, st.s));
+  HIP_TRY(hipMemsetAsync(dv.p, 0, (size_t)Nt * k.k1 * rs, st.s));
+  int rc;
+  if (real == SCTL_AMD_F64)
+    rc = eval_device_t<double>(k, real, Nt, Ns, (const double*)dxt.p, (const double*)dxs.p, (const double*)dxn.p, (const double*)df.p, (double*)dv.p,
+                               digits, ctx, st.s);
+  else
+    rc = eval_device_t<float>(k, real, Nt, Ns, (const float*)dxt.p, (const float*)dxs.p, (const float*)dxn.p, (const float*)df.p, (float*)dv.p, digits,
+                              ctx, st.s);
+  if (rc != SCTL_AMD_OK) return rc;
+  std::vector<char> out((size_t)Nt * k.k1 * rs);
+  HIP_TRY(hipMemcpyAsync(out.data(), dv.p, out.size(), hipMemcpyDeviceToHost, st.s));
+  HIP_TRY(hipStreamSynchronize(st.s));
+  // v_trg += device result (generic-kernel.txx:182-186; the scale factor was applied on the device)
+  const int64_t n = Nt * k.k1;
+  if (real == SCTL_AMD_F64) {
+    double* dst = (double*)v_trg + t0 * k.k1;
+    const double* src = (const double*)out.data();
+    for (int64_t i = 0; i < n; i++) dst[i] += src[i];
+  } else {
+    float* dst = (float*)v_trg + t0 * k.k1;
+    const float* src = (const float*)out.data();
+    for (int64_t i = 0; i < n; i++) dst[i] += src[i];
+  }
+  return SCTL_AMD_OK;
+}
+
+}  // namespace
+}  // namespace sctl_amd
+
+using namespace sctl_amd;
+
+extern "C" {
+
+int sctl_amd_version(void) { return SCTL_AMD_VERSION; }
+const char* sctl_amd_last_error(void) { return g_err.c_str(); }
+int sctl_amd_device_count(void) { return device_count_quiet(); }
+
+int sctl_amd_kernel_id(const char* name) {
+  if (!name) return SCTL_AMD_ERR_UNKNOWN_KERNEL;
+  for (int i = 0; i < SCTL_AMD_NUM_KERNELS; i++)
+    if (!std::strcmp(registry(i)->name, name)) return i;
+  return SCTL_AMD_ERR_UNKNOWN_KERNEL;
+}
+const char* sctl_amd_kernel_name(int kernel) {
+  const KernelEntry* k = registry(kernel);
+  return k ? k->name : nullptr;
+}
+int sctl_amd_kernel_info(int kernel, int* src_dim, int* trg_dim, int* normal_dim, int* flops, double* scale, int* ctx_bytes) {
+  const KernelEntry* k = registry(kernel);
+  if (!k) return fail(SCTL_AMD_ERR_UNKNOWN_KERNEL, "unknown kernel id");
+  if (src_dim) *src_dim = k->k0;
+  if (trg_dim) *trg_dim = k->k1;
+  if (normal_dim) *normal_dim = k->nd;
+  if (flops) *flops = k->flops;
+  if (scale) *scale = k->scale;
+  if (ctx_bytes) *ctx_bytes = k->ctx_bytes;
+  return SCTL_AMD_OK;
+}
+int sctl_amd_flops_per_pair(int kernel) {
+  const KernelEntry* k = registry(kernel);
+  return k ? 3 + k->flops + 2 * k->k0 * k->k1 : SCTL_AMD_ERR_UNKNOWN_KERNEL;
+}
+
+int sctl_amd_eval_device(int kernel, int real, int64_t Nt, int64_t Ns, const void* r_trg, const void* r_src, const void* n_src,
+                         const void* v_src, void* v_trg, int digits, const void* ctx, int ctx_bytes, void* stream) {
+  const KernelEntry* k = registry(kernel);
+  int rc = check_common(k, real, Nt, Ns, r_trg, r_src, n_src, ctx_bytes, ctx);
+  if (rc) return rc;
+  if ((Ns > 0 && !v_src) || (Nt > 0 && !v_trg)) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "null density or potential array");
+  if (device_count_quiet() <= 0) return fail(SCTL_AMD_ERR_NO_DEVICE, "no HIP device: libsctl_amd has no CPU fallback");
+  if (real == SCTL_AMD_F64)
+    return eval_device_t<double>(*k, real, Nt, Ns, (const double*)r_trg, (const double*)r_src, (const double*)n_src, (const double*)v_src,
+                                 (double*)v_trg, digits, ctx, (hipStream_t)stream);
+  return eval_device_t<float>(*k, real, Nt, Ns, (const float*)r_trg, (const float*)r_src, (const float*)n_src, (const float*)v_src, (float*)v_trg,
+                              digits, ctx, (hipStream_t)stream);
+}
+
+int sctl_amd_eval_host_multi(int kernel, int real, int64_t Nt, int64_t Ns, const void* r_trg, const void* r_src, const void* n_src,
+                             const void* v_src, void* v_trg, int digits, const void* ctx, int ctx_bytes, const int* devices, int n_devices) {
+  const KernelEntry* k = registry(kernel);
+  int rc = check_common(k, real, Nt, Ns, r_trg, r_src, n_src, ctx_bytes, ctx);
+  if (rc) return rc;
+  if ((Ns > 0 && !v_src) || (Nt > 0 && !v_trg)) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "null density or potential array");
+  const int avail = device_count_quiet();
+  if (avail <= 0) return fail(SCTL_AMD_ERR_NO_DEVICE, "no HIP device: libsctl_amd has no CPU fallback");
+  if (n_devices <= 0) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "n_devices must be positive");
+  std::vector<int> devs(n_devices);
+  for (int g = 0; g < n_devices; g++) {
+    devs[g] = devices ? devices[g] : g;
+    if (devs[g] < 0 || devs[g] >= avail) return fail(SCTL_AMD_ERR_NO_DEVICE, "device index " + std::to_string(devs[g]) + " out of range");
+  }
+  if (n_devices == 1) return eval_host_slab(*k, real, 0, Nt, Ns, r_trg, r_src, n_src, v_src, v_trg, digits, ctx, devs[0]);
+  // contiguous target slabs [Nt*g/G, Nt*(g+1)/G) (fmm-wrapper.txx:507), one host thread and one stream per GPU;
+  // slabs of v_trg are disjoint, so the threads share nothing but read-only inputs
+  std::vector<int> rcs(n_devices, SCTL_AMD_OK);
+  std::vector<std::string> msgs(n_devices);
+  std::vector<std::thread> th;
+  for (int g = 0; g < n_devices; g++) {
+    th.emplace_back([&, g] {
+      const int64_t t0 = Nt * g / n_devices, t1 = Nt * (g + 1) / n_devices;
+      rcs[g] = eval_host_slab(*k, real, t0, t1, Ns, r_trg, r_src, n_src, v_src, v_trg, digits, ctx, devs[g]);
+      if (rcs[g]) msgs[g] = g_err;
+    });
+  }
+  for (auto& t : th) t.join();
+  for (int g = 0; g < n_devices; g++)
+    if (rcs[g]) return fail(rcs[g], "device " + std::to_string(devs[g]) + ": " + msgs[g]);
+  return SCTL_AMD_OK;
+}
+
+int sctl_amd_eval_host(int kernel, int real, int64_t Nt, int64_t Ns, const void* r_trg, const void* r_src, const void* n_src,
+                       const void* v_src, void* v_trg, int digits, const void* ctx, int ctx_bytes, int device) {
+  return sctl_amd_eval_host_multi(kernel, real, Nt, Ns, r_trg, r_src, n_src, v_src, v_trg, digits, ctx, ctx_bytes, &device, 1);
+}
+
+int sctl_amd_kernel_matrix_device(int kernel, int real, int64_t Nt, int64_t Ns, const void* r_trg, const void* r_src, const void* n_src,
+                                  void* M, int digits, const void* ctx, int ctx_bytes, void* stream) {
+  const KernelEntry* k = registry(kernel);
+  int rc = check_common(k, real, Nt, Ns, r_trg, r_src, n_src, ctx_bytes, ctx);
+  if (rc) return rc;
+  if (Nt > 0 && Ns > 0 && !M) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "null matrix");
+  if (device_count_quiet() <= 0) return fail(SCTL_AMD_ERR_NO_DEVICE, "no HIP device: libsctl_amd has no CPU fallback");
+  if (real == SCTL_AMD_F64)
+    return matrix_device_t<double>(*k, real, Nt, Ns, (const double*)r_trg, (const double*)r_src, (const double*)n_src, (double*)M, digits, ctx,
+                                   (hipStream_t)stream);
+  return matrix_device_t<float>(*k, real, Nt, Ns, (const float*)r_trg, (const float*)r_src, (const float*)n_src, (float*)M, digits, ctx,
+                                (hipStream_t)stream);
+}
+
+int sctl_amd_kernel_matrix_host(int kernel, int real, int64_t Nt, int64_t Ns, const void* r_trg, const void* r_src, const void* n_src, void* M,
+                                int digits, const void* ctx, int ctx_bytes, int device) {
+  const KernelEntry* k = registry(kernel);
+  int rc = check_common(k, real, Nt, Ns, r_trg, r_src, n_src, ctx_bytes, ctx);
+  if (rc) return rc;
+  if (Nt > 0 && Ns > 0 && !M) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "null matrix");
+  const int avail = device_count_quiet();
+  if (avail <= 0) return fail(SCTL_AMD_ERR_NO_DEVICE, "no HIP device: libsctl_amd has no CPU fallback");
+  if (device < 0 || device >= avail) return fail(SCTL_AMD_ERR_NO_DEVICE, "device index out of range");
+  if (Nt == 0 || Ns == 0) return SCTL_AMD_OK;
+  const size_t rs = (real == SCTL_AMD_F64) ? 8 : 4;
+  HIP_TRY(hipSetDevice(device));
+  StreamGuard st;
+  HIP_TRY(hipStreamCreateWithFlags(&st.s, hipStreamNonBlocking));
+  DevBuf dxt, dxs, dxn, dm;
+  const size_t mbytes = (size_t)Ns * k->k0 * Nt * k->k1 * rs;
+  HIP_TRY(dxt.alloc((size_t)Nt * 3 * rs));
+  HIP_TRY(dxs.alloc((size_t)Ns * 3 * rs));
+  HIP_TRY(dxn.alloc((size_t)Ns * k->nd * rs));
+  HIP_TRY(dm.alloc(mbytes));
+  HIP_TRY(hipMemcpyAsync(dxt.p, r_trg, (size_t)Nt * 3 * rs, hipMemcpyHostToDevice, st.s));
+  HIP_TRY(hipMemcpyAsync(dxs.p, r_src, (size_t)Ns * 3 * rs, hipMemcpyHostToDevice, st.s));
+  if (k->nd) HIP_TRY(hipMemcpyAsync(dxn.p, n_src, (size_t)Ns * k->nd * rs, hipMemcpyHostToDevice, st.s));
+  rc = sctl_amd_kernel_matrix_device(kernel, real, Nt, Ns, dxt.p, dxs.p, dxn.p, dm.p, digits, ctx, ctx_bytes, st.s);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(M, dm.p, mbytes, hipMemcpyDeviceToHost, st.s));
+  HIP_TRY(hipStreamSynchronize(st.s));
+  return SCTL_AMD_OK;
+}
+
+void sctl_amd_counters(int64_t* pair_interactions, int64_t* sctl_flops) {
+  if (pair_interactions) *pair_interactions = g_pairs.load();
+  if (sctl_flops) *sctl_flops = g_flops.load();
+}
+void sctl_amd_reset_counters(void) { g_pairs = 0; g_flops = 0; }
+
+int sctl_amd_eval_plan(int kernel, int real, int64_t Nt, int64_t Ns, int digits, int* trg_per_lane, int* src_splits, int64_t* workgroups,
+                       int64_t* workspace_bytes) {
+  (void)digits;
+  const KernelEntry* k = registry(kernel);
+  if (!k) return fail(SCTL_AMD_ERR_UNKNOWN_KERNEL, "unknown kernel id");
+  if (real != SCTL_AMD_F64 && real != SCTL_AMD_F32) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "real must be SCTL_AMD_F64 or SCTL_AMD_F32");
+  if (Nt < 0 || Ns < 0) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "negative size");
+  const Plan p = make_plan(*k, real, Nt, Ns);
+  if (trg_per_lane) *trg_per_lane = kTvalues[p.t_idx];
+  if (src_splits) *src_splits = p.splits;
+  if (workgroups) *workgroups = p.wg_x * p.splits;
+  if (workspace_bytes) *workspace_bytes = p.workspace_bytes;
+  return SCTL_AMD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,192 @@
+// All-pairs evaluation kernels for gfx950 (MI355X): the device replacement of the loop nest in
+// GenericKernel<uKernel>::Eval (reference include/sctl/generic-kernel.txx:76-189).
+//
+// Work decomposition (nothing like the reference's "OpenMP over target SIMD blocks, serial over sources"):
+//   * a workgroup is 256 lanes = 4 wave64; each lane owns T targets in registers (coords + K1 accumulators);
+//   * grid.x tiles the targets (256*T per workgroup), grid.y splits the SOURCE range so that small target
+//     counts still fill 256 CUs; each split writes unscaled partial sums, a second kernel adds them in a fixed
+//     order (deterministic: no atomics) — with one split the main kernel accumulates into v_trg directly;
+//   * sources stream through LDS in tiles of 256 packed records (ukernels.hpp: pack()); a record is read back
+//     with ds_read_b128 at one address for the whole wave (LDS broadcast, no bank conflicts) and reused for
+//     the T targets of the lane.
+// The kernel is fp64/fp32 VALU-bound by five orders of magnitude over its HBM traffic,
+// so there is no double buffering of the tile: the tile fill is < 1 % of the tile's compute and other
+// resident workgroups cover it.
+#pragma once
+#include "ukernels.hpp"
+
+namespace sctl_amd {
+
+constexpr int kBlock = 256;   // lanes per workgroup
+constexpr int kTile = 256;    // sources per LDS tile (one per lane at fill time)
+
+template <class R> struct EvalArgs {
+  int64_t Nt, Ns;
+  const R* xt;      // [Nt*3]
+  const R* xs;      // [Ns*3]
+  const R* xn;      // [Ns*ND] or null
+  const R* f;       // [Ns*K0]
+  R* v_trg;         // [Nt*K1], accumulated into (only touched by the main kernel when gridDim.y == 1)
+  R* partial;       // [gridDim.y][Nt*K1] unscaled partial sums when gridDim.y > 1
+  int64_t chunk;    // sources per split, a multiple of kTile
+  R scale;
+  KerCtx ctx;
+};
+
+template <class R> struct VecOf;
+template <> struct VecOf<double> { typedef double type __attribute__((ext_vector_type(2))); static constexpr int N = 2; };
+template <> struct VecOf<float> { typedef float type __attribute__((ext_vector_type(4))); static constexpr int N = 4; };
+
+// TWO_LEVEL: keep a per-tile accumulator and add it to the running sum once per tile (pairwise-style
+// summation; bounds fp32 error growth at Ns = 2^23, SURVEY.md §7 "fp32 at N=8M").
+template <class Ker, class R, int MODE, int T, bool TWO_LEVEL>
+__global__ void __launch_bounds__(kBlock) eval_kernel(const EvalArgs<R> a) {
+  constexpr int K0 = Ker::K0, K1 = Ker::K1, ND = Ker::ND, NREC = Ker::NREC;
+  using V = typename VecOf<R>::type;
+  constexpr int VN = VecOf<R>::N;
+  constexpr int NV = (NREC + VN - 1) / VN;     // 16-byte LDS words per record
+  constexpr int NRECP = NV * VN;               // record padded to whole words (fp32: multiples of 4 reals)
+  constexpr int UNROLL = (T >= 4 || K1 > 4) ? 1 : (T == 2 ? 2 : 4);   // ~4 independent pair chains in flight
+  __shared__ V tile[kTile * NV];
+
+  const int tid = threadIdx.x;
+  const int64_t tbase = (int64_t)blockIdx.x * (kBlock * T);
+  const RsqConst<R> K;
+
+  R xt[T][3], acc[T][K1];
+#pragma unroll
+  for (int j = 0; j < T; j++) {
+    int64_t t = tbase + j * kBlock + tid;
+    if (t >= a.Nt) t = a.Nt - 1;   // tail lanes recompute the last target; never stored
+#pragma unroll
+    for (int k = 0; k < 3; k++) xt[j][k] = a.xt[t * 3 + k];
+#pragma unroll
+    for (int k = 0; k < K1; k++) acc[j][k] = 0;
+  }
+
+  const int64_t s_begin = (int64_t)blockIdx.y * a.chunk;
+  const int64_t s_end = (s_begin + a.chunk < a.Ns) ? s_begin + a.chunk : a.Ns;
+  const int64_t len = (s_end > s_begin) ? s_end - s_begin : 0;
+  const int ntile = (int)((len + kTile - 1) / kTile);
+
+  for (int it = 0; it < ntile; it++) {
+    const int64_t s0 = s_begin + (int64_t)it * kTile;
+    const int ns = (it == ntile - 1) ? (int)(len - (int64_t)it * kTile) : kTile;   // wave-uniform
+    __syncthreads();   // previous tile fully consumed
+    if (tid < ns) {
+      const int64_t s = s0 + tid;
+      R x[3], n[3] = {0, 0, 0}, f[K0], rec[NRECP] = {};
+#pragma unroll
+      for (int k = 0; k < 3; k++) x[k] = a.xs[s * 3 + k];
+#pragma unroll
+      for (int k = 0; k < ND; k++) n[k] = a.xn[s * ND + k];
+#pragma unroll
+      for (int k = 0; k < K0; k++) f[k] = a.f[s * K0 + k];
+      Ker::template pack<R>(rec, x, n, f);
+#pragma unroll
+      for (int v = 0; v < NV; v++) {
+        V w;
+#pragma unroll
+        for (int e = 0; e < VN; e++) w[e] = rec[v * VN + e];
+        tile[tid * NV + v] = w;
+      }
+    }
+    __syncthreads();
+
+    R tacc[T][K1];   // dead (removed by the compiler) unless TWO_LEVEL
+    if constexpr (TWO_LEVEL) {
+#pragma unroll
+      for (int j = 0; j < T; j++)
+#pragma unroll
+        for (int k = 0; k < K1; k++) tacc[j][k] = 0;
+    }
+    // one source against the T targets of this lane; the record is read at ONE LDS address by the whole
+    // wave (broadcast) and kept in registers for the T pair evaluations
+    auto one_source = [&](int s) {
+      R rec[NRECP];
+#pragma unroll
+      for (int v = 0; v < NV; v++) {
+        const V w = tile[s * NV + v];
+#pragma unroll
+        for (int e = 0; e < VN; e++) rec[v * VN + e] = w[e];
+      }
+#pragma unroll
+      for (int j = 0; j < T; j++) {
+        const R d[3] = {xt[j][0] - rec[0], xt[j][1] - rec[1], xt[j][2] - rec[2]};
+        if constexpr (TWO_LEVEL) Ker::template pair<R, MODE>(tacc[j], d, rec, a.ctx, K);
+        else Ker::template pair<R, MODE>(acc[j], d, rec, a.ctx, K);
+      }
+    };
+    if (ns == kTile) {   // every tile but possibly the last: constant trip count, unrolled
+#pragma unroll UNROLL
+      for (int s = 0; s < kTile; s++) one_source(s);
+    } else {
+      for (int s = 0; s < ns; s++) one_source(s);
+    }
+    if constexpr (TWO_LEVEL) {
+#pragma unroll
+      for (int j = 0; j < T; j++)
+#pragma unroll
+        for (int k = 0; k < K1; k++) acc[j][k] += tacc[j][k];
+    }
+  }
+
+#pragma unroll
+  for (int j = 0; j < T; j++) {
+    const int64_t t = tbase + j * kBlock + tid;
+    if (t < a.Nt) {
+      if (gridDim.y == 1) {
+#pragma unroll
+        for (int k = 0; k < K1; k++) a.v_trg[t * K1 + k] += acc[j][k] * a.scale;   // generic-kernel.txx:184
+      } else {
+        R* p = a.partial + ((int64_t)blockIdx.y * a.Nt + t) * K1;
+#pragma unroll
+        for (int k = 0; k < K1; k++) p[k] = acc[j][k];
+      }
+    }
+  }
+}
+
+// v_trg[i] += scale * sum_y partial[y][i], y in increasing order (deterministic).
+template <class R> __global__ void __launch_bounds__(kBlock) reduce_splits_kernel(R* v_trg, const R* partial, int64_t n, int splits, R scale) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  R s = 0;
+  for (int y = 0; y < splits; y++) s += partial[(int64_t)y * n + i];
+  v_trg[i] += s * scale;
+}
+
+// Dense operator block, GenericKernel::KernelMatrix (generic-kernel.txx:191-307):
+//   M[(s*K0 + k0)][(t*K1 + k1)] = scale * U(x_t - x_s, n_s)[k0][k1],   M is (Ns*K0) x (Nt*K1), overwritten.
+// One lane per (s, t) pair, t fastest so that stores of one k0,k1 plane are K1-strided runs; the matrix is
+// output-bandwidth bound (K0*K1*sizeof(R) bytes per pair), so no LDS staging of inputs is needed.
+// U[k0][k1] is obtained by feeding unit densities through the same pair() routine the evaluator uses.
+template <class Ker, class R, int MODE>
+__global__ void __launch_bounds__(kBlock) matrix_kernel(int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* xn, R* M, R scale, KerCtx ctx) {
+  constexpr int K0 = Ker::K0, K1 = Ker::K1, ND = Ker::ND, NREC = Ker::NREC;
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= Nt) return;
+  const RsqConst<R> K;
+  for (int64_t s = blockIdx.y; s < Ns; s += gridDim.y) {   // gridDim.y is capped at 65535
+  R x[3], n[3] = {0, 0, 0}, d[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) { x[k] = xs[s * 3 + k]; d[k] = xt[t * 3 + k] - x[k]; }
+#pragma unroll
+  for (int k = 0; k < ND; k++) n[k] = xn[s * ND + k];
+#pragma unroll
+  for (int k0 = 0; k0 < K0; k0++) {
+    R f[K0], rec[NREC], acc[K1];
+#pragma unroll
+    for (int k = 0; k < K0; k++) f[k] = (k == k0) ? R(1) : R(0);
+#pragma unroll
+    for (int k = 0; k < K1; k++) acc[k] = 0;
+    Ker::template pack<R>(rec, x, n, f);
+    Ker::template pair<R, MODE>(acc, d, rec, ctx, K);
+    R* row = M + ((s * K0 + k0) * Nt + t) * K1;
+#pragma unroll
+    for (int k = 0; k < K1; k++) row[k] = acc[k] * scale;
+  }
+  }
+}
+
+}  // namespace sctl_amd

@@ -1,0 +1,255 @@
+// Device micro-kernels for gfx950: one struct per Green's function.
+//
+// Each struct replaces one functor of the reference's include/sctl/kernel_functions.hpp (cited per struct)
+// but is NOT a transcription: the reference builds the K0 x K1 matrix U and then does K0*K1 FMAs
+// (generic-kernel.txx:81-90); here every kernel is the contracted form  acc[k1] += sum_k0 U[k0][k1] f[k0]
+// written with the fewest fp64 VALU instructions (MI355X fp64 FMA issues at 4 cycles per wave64, the
+// reciprocal-square-root seed at 16 — tools/ubench/valu_rates.hip), and source records are pre-packed in
+// LDS (e.g. normal*density for double-layer kernels) so that the per-pair work is minimal.
+//
+// Interface used by eval_kernel.hpp:
+//   K0, K1, ND          SrcDim, TrgDim, NormalDim (generic-kernel.hpp:59-84)
+//   NREC                reals per packed source record in LDS (multiple of 16 bytes for R = double and float)
+//   FLOPS, scale()      kernel_functions.hpp FLOPS() / uKerScaleFactor
+//   pack(rec, x, n, f)  build the LDS record of one source from the AoS inputs
+//   pair<R,MODE>(acc, d, rec, ctx, K)   one pair interaction, d = x_trg - x_src  (generic-kernel.txx:83)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sctl_amd {
+
+constexpr double kPi = 3.141592653589793238462643383279502884;
+
+// Kernel context passed by value in the launch arguments (replaces the host ctx_ptr, generic-kernel.hpp:150).
+struct KerCtx { double v[4]; };
+
+// ---- masked reciprocal square root ---------------------------------------------------------------------
+// Semantics of approx_rsqrt<digits>(r2, r2 > 0) (vec.txx:361-364, intrin-wrapper.hpp:539-555): 0 where
+// r2 == 0, else r2^-1/2 to `digits` digits.  The seed is the hardware v_rsq_f64 / v_rsq_f32 (measured max
+// relative error 2^-24.2 / 2^-23.3, tools/ubench/rsq_accuracy.hip); v_rsq(0) = +inf, whose high word is
+// replaced by 0 with two 32-bit VALU ops (the low word of +inf is already 0).  Refinement, with
+// e = 1 - x y^2 computed by one FMA so that it is exact to fp64 rounding:
+//   MODE 0: seed only                                (>= 7 digits)
+//   MODE 1: one Newton step,  y + y e / 2            (error 3/8 e^2 ~ 1e-15, >= 14 digits)
+//   MODE 2: one Halley step,  y + y e (1/2 + 3/8 e)  (error O(e^3): rounding only)
+// With y = 0 every refinement returns 0, so the mask survives; NaN/inf inputs propagate as in the reference.
+// The one constant that is not a hardware inline constant (3/8) lives in a VGPR pair for the whole kernel
+// (RsqConst, made opaque to the optimiser so that it is not re-materialised with v_mov per use).
+template <class R> struct RsqConst {
+  R c38;
+  __device__ __forceinline__ RsqConst() : c38(R(0.375)) { asm volatile("" : "+v"(c38)); }
+};
+
+template <int MODE> __device__ __forceinline__ double rsqrt_masked(double r2, const RsqConst<double>& K) {
+  double y = __builtin_amdgcn_rsq(r2);
+  // r2 == 0 -> y = +inf = {hi 0x7ff00000, lo 0} -> 0: one 32-bit compare + one v_cndmask on the high word.
+  // The empty asm only stops the optimiser from widening this into a 64-bit compare; the compare and select
+  // themselves are compiler-generated so that the gfx950 trans->VALU hazard after v_rsq_f64 is padded correctly
+  // (an asm block reading the v_rsq result directly is NOT padded and read a stale register: observed as a NaN).
+  int hi = __double2hiint(y);
+  asm("" : "+v"(hi));
+  hi = (hi == 0x7ff00000) ? 0 : hi;
+  y = __hiloint2double(hi, __double2loint(y));
+  if (MODE >= 1) {
+    const double a = r2 * y;
+    const double e = __builtin_fma(-a, y, 1.0);
+    const double ye = y * e;
+    if (MODE == 1) y = __builtin_fma(ye, 0.5, y);
+    else y = __builtin_fma(ye, __builtin_fma(e, K.c38, 0.5), y);
+  }
+  return y;
+}
+template <int MODE> __device__ __forceinline__ float rsqrt_masked(float r2, const RsqConst<float>&) {
+  float y = __builtin_amdgcn_rsqf(r2);
+  y = (__float_as_uint(y) == 0x7f800000u) ? 0.0f : y;   // r2 == 0 -> +inf -> 0
+  if (MODE >= 1) {   // one Newton step in fp32 (only when more than 7 digits are asked of fp32)
+    const float a = r2 * y;
+    const float e = __builtin_fmaf(-a, y, 1.0f);
+    y = __builtin_fmaf(y * e, 0.5f, y);
+  }
+  return y;
+}
+
+template <class R> __device__ __forceinline__ R fma_(R a, R b, R c);
+template <> __device__ __forceinline__ double fma_<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
+template <> __device__ __forceinline__ float fma_<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+template <class R> __device__ __forceinline__ R len2(const R (&d)[3]) { return fma_(d[2], d[2], fma_(d[1], d[1], d[0] * d[0])); }
+template <class R> __device__ __forceinline__ R dot3(const R (&d)[3], const R* v) { return fma_(d[2], v[2], fma_(d[1], v[1], d[0] * v[0])); }
+
+// ---- Laplace single layer: u = f / r          (kernel_functions.hpp:15-31) -------------------------------
+struct Laplace3D_FxU {
+  static constexpr int ID = 0, K0 = 1, K1 = 1, ND = 0, NREC = 4, FLOPS = 6;
+  static constexpr const char* NAME = "Laplace3D-FxU";
+  static constexpr double scale() { return 1 / (4 * kPi); }
+  template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
+    rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0];
+  }
+  template <class R, int MODE> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const RsqConst<R>& K) {
+    const R rinv = rsqrt_masked<MODE>(len2(d), K);
+    acc[0] = fma_(rec[3], rinv, acc[0]);
+  }
+};
+
+// ---- Laplace double layer: u = (r.n) f / r^3   (kernel_functions.hpp:33-51); record holds n*f ------------
+struct Laplace3D_DxU {
+  static constexpr int ID = 1, K0 = 1, K1 = 1, ND = 3, NREC = 6, FLOPS = 14;
+  static constexpr const char* NAME = "Laplace3D-DxU";
+  static constexpr double scale() { return 1 / (4 * kPi); }
+  template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R* n, const R* f) {
+    rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = n[0] * f[0]; rec[4] = n[1] * f[0]; rec[5] = n[2] * f[0];
+  }
+  template <class R, int MODE> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const RsqConst<R>& K) {
+    const R rinv = rsqrt_masked<MODE>(len2(d), K);
+    const R rinv3 = rinv * rinv * rinv;
+    acc[0] = fma_(dot3(d, rec + 3), rinv3, acc[0]);
+  }
+};
+
+// ---- gradient of the Laplace single layer: u_j = f r_j / r^3, scale -1/(4 pi)   (kernel_functions.hpp:53-72)
+struct Laplace3D_FxdU {
+  static constexpr int ID = 2, K0 = 1, K1 = 3, ND = 0, NREC = 4, FLOPS = 11;
+  static constexpr const char* NAME = "Laplace3D-FxdU";
+  static constexpr double scale() { return -1 / (4 * kPi); }
+  template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
+    rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0];
+  }
+  template <class R, int MODE> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const RsqConst<R>& K) {
+    const R rinv = rsqrt_masked<MODE>(len2(d), K);
+    const R t = rinv * rinv * rinv * rec[3];
+    for (int j = 0; j < 3; j++) acc[j] = fma_(t, d[j], acc[j]);
+  }
+};
+
+// ---- Stokeslet: u_j = f_j / r + (r.f) r_j / r^3, scale 1/(8 pi)   (kernel_functions.hpp:74-95) -----------
+struct Stokes3D_FxU {
+  static constexpr int ID = 3, K0 = 3, K1 = 3, ND = 0, NREC = 6, FLOPS = 23;
+  static constexpr const char* NAME = "Stokes3D-FxU";
+  static constexpr double scale() { return 1 / (8 * kPi); }
+  template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
+    rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0]; rec[4] = f[1]; rec[5] = f[2];
+  }
+  template <class R, int MODE> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const RsqConst<R>& K) {
+    const R rinv = rsqrt_masked<MODE>(len2(d), K);
+    const R t = dot3(d, rec + 3) * (rinv * rinv * rinv);
+    for (int j = 0; j < 3; j++) acc[j] = fma_(t, d[j], fma_(rinv, rec[3 + j], acc[j]));
+  }
+};
+
+// ---- stresslet: u_j = r_j (r.f)(r.n) / r^5, scale 3/(4 pi)   (kernel_functions.hpp:97-120) ----------------
+struct Stokes3D_DxU {
+  static constexpr int ID = 4, K0 = 3, K1 = 3, ND = 3, NREC = 10, FLOPS = 26;
+  static constexpr const char* NAME = "Stokes3D-DxU";
+  static constexpr double scale() { return 3 / (4 * kPi); }
+  template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R* n, const R* f) {
+    for (int k = 0; k < 3; k++) { rec[k] = x[k]; rec[3 + k] = n[k]; rec[6 + k] = f[k]; }
+    rec[9] = 0;
+  }
+  template <class R, int MODE> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const RsqConst<R>& K) {
+    const R rinv = rsqrt_masked<MODE>(len2(d), K);
+    const R rinv2 = rinv * rinv;
+    const R t = dot3(d, rec + 3) * dot3(d, rec + 6) * (rinv2 * rinv2 * rinv);
+    for (int j = 0; j < 3; j++) acc[j] = fma_(t, d[j], acc[j]);
+  }
+};
+
+// ---- traction tensor: u_{jk} = (r.f) r_j r_k / r^5, scale -3/(4 pi)   (kernel_functions.hpp:122-146) -------
+struct Stokes3D_FxT {
+  static constexpr int ID = 5, K0 = 3, K1 = 9, ND = 0, NREC = 6, FLOPS = 39;
+  static constexpr const char* NAME = "Stokes3D-FxT";
+  static constexpr double scale() { return -3 / (4 * kPi); }
+  template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
+    rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0]; rec[4] = f[1]; rec[5] = f[2];
+  }
+  template <class R, int MODE> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const RsqConst<R>& K) {
+    const R rinv = rsqrt_masked<MODE>(len2(d), K);
+    const R rinv2 = rinv * rinv;
+    const R t = dot3(d, rec + 3) * (rinv2 * rinv2 * rinv);
+    for (int j = 0; j < 3; j++) {
+      const R tj = t * d[j];
+      for (int k = 0; k < 3; k++) acc[j * 3 + k] = fma_(tj, d[k], acc[j * 3 + k]);
+    }
+  }
+};
+
+// ---- Stokeslet + source/sink: u_j = f_j / r + ((r.f) + f_3) r_j / r^3   (kernel_functions.hpp:148-172) ------
+struct Stokes3D_FSxU {
+  static constexpr int ID = 6, K0 = 4, K1 = 3, ND = 0, NREC = 8, FLOPS = 26;
+  static constexpr const char* NAME = "Stokes3D-FSxU";
+  static constexpr double scale() { return 1 / (8 * kPi); }
+  template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
+    rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0]; rec[4] = f[1]; rec[5] = f[2]; rec[6] = f[3]; rec[7] = 0;
+  }
+  template <class R, int MODE> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const RsqConst<R>& K) {
+    const R rinv = rsqrt_masked<MODE>(len2(d), K);
+    const R t = (dot3(d, rec + 3) + rec[6]) * (rinv * rinv * rinv);
+    for (int j = 0; j < 3; j++) acc[j] = fma_(t, d[j], fma_(rinv, rec[3 + j], acc[j]));
+  }
+};
+
+// ---- velocity + pressure: Stokeslet and p = (r.f) / r^3   (kernel_functions.hpp:174-198) -------------------
+struct Stokes3D_FxUP {
+  static constexpr int ID = 7, K0 = 3, K1 = 4, ND = 0, NREC = 6, FLOPS = 26;
+  static constexpr const char* NAME = "Stokes3D-FxUP";
+  static constexpr double scale() { return 1 / (8 * kPi); }
+  template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
+    rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0]; rec[4] = f[1]; rec[5] = f[2];
+  }
+  template <class R, int MODE> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const RsqConst<R>& K) {
+    const R rinv = rsqrt_masked<MODE>(len2(d), K);
+    const R t = dot3(d, rec + 3) * (rinv * rinv * rinv);
+    for (int j = 0; j < 3; j++) acc[j] = fma_(t, d[j], fma_(rinv, rec[3 + j], acc[j]));
+    acc[3] += t;
+  }
+};
+
+// ---- NEW: Laplace single + double layer -> potential and gradient (BASELINE config 2) -----
+//   u      = q / r + mu (r.n) / r^3
+//   grad u = -q r / r^3 + mu ( n / r^3 - 3 (r.n) r / r^5 ),    scale 1/(4 pi);  record holds m = mu * n and q.
+struct Laplace3D_FDxUdU {
+  static constexpr int ID = 8, K0 = 2, K1 = 4, ND = 3, NREC = 8, FLOPS = 28;
+  static constexpr const char* NAME = "Laplace3D-FDxUdU";
+  static constexpr double scale() { return 1 / (4 * kPi); }
+  template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R* n, const R* f) {
+    rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2];
+    rec[3] = n[0] * f[1]; rec[4] = n[1] * f[1]; rec[5] = n[2] * f[1]; rec[6] = f[0]; rec[7] = 0;
+  }
+  template <class R, int MODE> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const RsqConst<R>& K) {
+    const R rinv = rsqrt_masked<MODE>(len2(d), K);
+    const R rinv2 = rinv * rinv;
+    const R rinv3 = rinv2 * rinv;
+    const R a = dot3(d, rec + 3) * rinv3;               // mu (r.n) / r^3
+    acc[0] = fma_(rec[6], rinv, acc[0]) + a;
+    const R b = fma_(R(-3) * a, rinv2, -(rec[6] * rinv3));   // -(q / r^3 + 3 mu (r.n) / r^5)
+    for (int j = 0; j < 3; j++) acc[1 + j] = fma_(d[j], b, fma_(rec[3 + j], rinv3, acc[1 + j]));
+  }
+};
+
+// ---- NEW: Helmholtz single layer G = exp(ikr)/r, complex k = ctx.v[0] + i ctx.v[1] (config 5)
+//   (u_re, u_im) += G (f_re, f_im) as complex numbers, scale 1/(4 pi), G = 0 at r = 0.
+struct Helmholtz3D_FxU {
+  static constexpr int ID = 9, K0 = 2, K1 = 2, ND = 0, NREC = 6, FLOPS = 16;
+  static constexpr const char* NAME = "Helmholtz3D-FxU";
+  static constexpr double scale() { return 1 / (4 * kPi); }
+  template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
+    rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0]; rec[4] = f[1]; rec[5] = 0;
+  }
+  template <class R, int MODE> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx& ctx, const RsqConst<R>& K) {
+    const R r2 = len2(d);
+    const R rinv = rsqrt_masked<MODE>(r2, K);
+    const R r = r2 * rinv;
+    R sn, cs;
+    sincos_(R(ctx.v[0]) * r, sn, cs);
+    const R amp = exp_(-R(ctx.v[1]) * r) * rinv;
+    const R gr = amp * cs, gi = amp * sn;
+    acc[0] = fma_(gr, rec[3], fma_(-gi, rec[4], acc[0]));
+    acc[1] = fma_(gi, rec[3], fma_(gr, rec[4], acc[1]));
+  }
+  static __device__ __forceinline__ void sincos_(double x, double& s, double& c) { ::sincos(x, &s, &c); }
+  static __device__ __forceinline__ void sincos_(float x, float& s, float& c) { ::sincosf(x, &s, &c); }
+  static __device__ __forceinline__ double exp_(double x) { return ::exp(x); }
+  static __device__ __forceinline__ float exp_(float x) { return ::expf(x); }
+};
+
+}  // namespace sctl_amd
