@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Headline benchmark: pair-interactions/s of the Laplace single-layer N x N direct sum on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload laplace_sl|laplace_sldl|stokeslet|helmholtz|laplace_sl_f32]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one full evaluation of the hot path over one synthetic point cloud that is already resident in HBM:
+zero the potential, run GenericKernel::Eval's device replacement over all pairs, (N > 1) all-gather the slabs.
+At N = 1 the workload is BASELINE.json's headline: Laplace3D single layer, 2^20 sources x 2^20 targets, fp64.
+For N > 1 the SAME problem is split: targets are block-partitioned over the ranks, sources replicated, one RCCL
+all-gather of the potential slabs per step (strong scaling: north_star asks for >= 6x at 8 GPUs on this problem).
+
+Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` and, at N = 1, `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (kernel, N, dtype, description)
+    "laplace_sl": ("Laplace3D-FxU", 1 << 20, "f64", "Laplace3D single layer (Laplace3D-FxU), 2^20 x 2^20, fp64 [BASELINE headline / north_star target]"),
+    "laplace_sldl": ("Laplace3D-FDxUdU", 1 << 20, "f64", "Laplace3D SL+DL potential+gradient (Laplace3D-FDxUdU), 2^20 x 2^20, fp64 [BASELINE configs[1]]"),
+    "stokeslet": ("Stokes3D-FxU", 1 << 18, "f64", "Stokes3D Stokeslet (Stokes3D-FxU), 2^18 x 2^18, fp64 [BASELINE configs[2]]"),
+    "laplace_sl_f32": ("Laplace3D-FxU", 1 << 23, "f32", "Laplace3D single layer, 2^23 x 2^23, fp32 [BASELINE configs[3]; needs >= 8 GPUs to finish in minutes]"),
+    "helmholtz": ("Helmholtz3D-FxU", 1 << 20, "f64", "Helmholtz3D single layer k = 7.5 + 0.3i (Helmholtz3D-FxU), 2^20 x 2^20, fp64 [BASELINE configs[4]]"),
+    "laplace_sl_16k": ("Laplace3D-FxU", 1 << 14, "f64", "Laplace3D single layer, 2^14 x 2^14, fp64 [BASELINE configs[0], the reference's CPU-runnable case]"),
+}
+PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}   # vector FMA peaks, BASELINE.md §3 / MI355X_MICROARCH.md chip table
+
+
+def cpu_baseline(kernel, N, dtype, budget_s=12.0):
+    """The reference's own OpenMP + Vec<> path (oracle/_ref, kind "reference") — or the CPU restatement ("port") when the
+    compiled reference is not usable on this host — timed on a bounded target subset against ALL sources."""
+    import oracle
+    impl = oracle.reference() or oracle.restatement()
+    info = impl.info(kernel)
+    dt = np.float64 if dtype == "f64" else np.float32
+    rng = np.random.default_rng(0)
+    xs = rng.random(N * 3).astype(dt)
+    xn = (rng.random(N * info["nd"]) - 0.5).astype(dt)
+    f = (rng.random(N * info["k0"]) - 0.5).astype(dt)
+    ctx = np.array([7.5, 0.3]) if kernel.startswith("Helmholtz") else None
+
+    def run(nt):
+        xt = rng.random(nt * 3).astype(dt)
+        t = time.perf_counter()
+        impl.eval(kernel, xt, xs, xn, f, ctx=ctx)
+        return time.perf_counter() - t
+
+    nt0 = max(64, min(N, (1 << 32) // N))
+    run(nt0)                                  # thread pool / page warm-up
+    rate = nt0 * N / run(nt0)
+    nt = int(min(N, max(nt0, budget_s * rate / N)))
+    nt -= nt % 64
+    secs = run(nt)
+    return {"value": nt * N / secs, "unit": "pair-interactions/s", "cores": impl.num_threads(), "kind": impl.kind,
+            "isa": getattr(impl, "isa", "x86-64-v3"),
+            "sample": "%d targets x %d sources (all sources, target subset; work is linear in targets), %.1f s, %s" % (nt, N, secs, kernel)}
+
+
+def read_traffic(workload):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/hbm_traffic.json), or None."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        with open(path) as fh:
+            return json.load(fh).get(workload, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="laplace_sl", choices=sorted(WORKLOADS))
+    ap.add_argument("--digits", type=int, default=-1, help="accuracy request; -1 = full precision (the reference default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import sctl_amd
+    from sctl_amd.distributed import ShardedDirectSum, slab_bounds
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: sctl_amd has no CPU path to measure")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    kernel, N, dtype, desc = WORKLOADS[args.workload]
+    info = sctl_amd.kernel_info(kernel)
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    ctx = np.array([7.5, 0.3]) if kernel.startswith("Helmholtz") else None
+
+    # synthetic uniform-random point cloud, identical on every rank (sources are replicated), resident in HBM
+    g = torch.Generator(device="cuda").manual_seed(0)
+    dev = torch.device("cuda", local_rank)
+    r_trg = torch.rand(N * 3, dtype=tdt, device=dev, generator=g)
+    r_src = torch.rand(N * 3, dtype=tdt, device=dev, generator=g)
+    n_src = torch.rand(N * info["nd"], dtype=tdt, device=dev, generator=g) - 0.5
+    v_src = torch.rand(N * info["k0"], dtype=tdt, device=dev, generator=g) - 0.5
+    t0, t1 = slab_bounds(N, rank, world)
+    out = torch.empty(N * info["k1"], dtype=tdt, device=dev)
+    out_slab = torch.empty((t1 - t0) * info["k1"], dtype=tdt, device=dev)
+    op = ShardedDirectSum(kernel, ctx=ctx, digits=args.digits)
+
+    kern_ms = []   # device time of the evaluation launches of each timed step, HIP events on the launch stream
+
+    def step(timed):
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            out_slab.zero_()
+            e0.record()
+            op.local_eval(r_trg[t0 * 3:t1 * 3], r_src, n_src, v_src, out_slab)
+            e1.record()
+            kern_ms.append((e0, e1))
+        else:
+            out_slab.zero_()
+            op.local_eval(r_trg[t0 * 3:t1 * 3], r_src, n_src, v_src, out_slab)
+        if world > 1:
+            dist.all_gather_into_tensor(out, out_slab)
+        return out if world > 1 else out_slab
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    tic = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    elapsed = time.perf_counter() - tic
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    pairs_per_step = float(N) * float(N)                 # all ranks together
+    value = pairs_per_step / (elapsed / args.steps)
+    fpp = sctl_amd.flops_per_pair(kernel)                # 3 + FLOPS() + 2*SrcDim*TrgDim
+    k_ms = float(np.mean([a.elapsed_time(b) for a, b in kern_ms]))
+    local_pairs = float(t1 - t0) * float(N)              # pairs ONE launch (this rank) processes
+    achieved = local_pairs * fpp / (k_ms * 1e-3) / 1e12
+    peak = PEAK_TFLOPS[dtype]
+    plan = sctl_amd.plan(kernel, 0 if dtype == "f64" else 1, t1 - t0, N, args.digits)
+
+    if rank == 0:
+        line = {
+            "metric": "pair-interactions/s, Laplace-SL N x N direct sum" if args.workload.startswith("laplace_sl") else "pair-interactions/s",
+            "value": value, "unit": "pair-interactions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": dtype, "data": "synthetic",
+            "config": {"workload": desc, "kernel": kernel, "n_trg": N, "n_src": N, "digits": args.digits,
+                       "partition": "targets block-partitioned over %d GPU(s), sources replicated, %s" %
+                                    (world, "one RCCL all-gather of the potential slabs per step" if world > 1 else "no collective"),
+                       "launch": plan},
+            "roofline": {"bound": "fp64_valu" if dtype == "f64" else "fp32_valu", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": read_traffic(args.workload) if world == 1 else None,
+                         "flops_per_pair": fpp, "kernel_ms": k_ms,
+                         "note": "vector-FMA bound (SURVEY.md §8d): algorithmic flops = pairs x (3 + FLOPS() + 2 K0 K1); "
+                                 "HBM traffic is ~6e-5 B/pair; achieved is per GPU from HIP-event kernel time"},
+            "sctl_gflops": value * info["flops"] / 1e9,   # the reference's own Profile convention (generic-kernel.txx:188)
+            "pct_of_peak_all_gpus": 100.0 * value * fpp / (peak * 1e12 * world),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(kernel, N, dtype)
+            except Exception as e:   # the baseline is reported, never required for the GPU number
+                line["cpu_baseline"] = {"value": None, "unit": "pair-interactions/s", "cores": 0, "kind": "unavailable", "sample": repr(e)}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

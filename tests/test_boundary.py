@@ -1,0 +1,112 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads and exports exactly what include/sctl_amd.h
+declares, argument errors are reported (no compute happens without a GPU), the launch planner is sane, and the
+product tree never touches oracle/."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import sctl_amd
+from conftest import ROOT
+from sctl_amd import api
+
+
+def _header_functions():
+    txt = open(os.path.join(ROOT, "include", "sctl_amd.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(sctl_amd_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    declared = _header_functions()
+    assert declared == sorted(api.SYMBOLS)
+    L = sctl_amd.lib()
+    for sym in declared:
+        assert hasattr(L, sym), sym
+    # and nothing C++-mangled leaks as the public surface: the declared names resolve as plain C symbols
+    out = subprocess.run(["nm", "-D", "--defined-only", sctl_amd.library_path()], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (sctl_amd_[a-z_0-9]+)$", out, flags=re.M))
+    assert set(declared) <= exported
+
+
+def test_version_and_registry():
+    L = sctl_amd.lib()
+    assert L.sctl_amd_version() >= 100
+    assert L.sctl_amd_kernel_id(b"Laplace3D-FxU") == 0
+    assert L.sctl_amd_kernel_id(b"NoSuchKernel") < 0           # the "is it supported" query
+    assert L.sctl_amd_kernel_name(99) is None
+    for i, name in enumerate(sctl_amd.KERNEL_NAMES):
+        assert sctl_amd.kernel_info(name)["id"] == i
+    assert sctl_amd.kernel_info("Helmholtz3D-FxU")["ctx_bytes"] == 16
+    with pytest.raises(KeyError):
+        sctl_amd.kernel_id("Laplace3D-SL")
+
+
+def test_argument_errors_before_any_device_work():
+    L = sctl_amd.lib()
+    z = np.zeros(3)
+    p = z.ctypes.data_as(ctypes.c_void_p)
+    # unknown kernel, bad precision tag, negative size, missing normals, missing context
+    assert L.sctl_amd_eval_host(99, 0, 1, 1, p, p, None, p, p, -1, None, 0, 0) == -1
+    assert L.sctl_amd_eval_host(0, 7, 1, 1, p, p, None, p, p, -1, None, 0, 0) == -2
+    assert L.sctl_amd_eval_host(0, 0, -1, 1, p, p, None, p, p, -1, None, 0, 0) == -2
+    assert L.sctl_amd_eval_host(1, 0, 1, 1, p, p, None, p, p, -1, None, 0, 0) == -2
+    assert b"normals" in L.sctl_amd_last_error()
+    assert L.sctl_amd_eval_host(9, 0, 1, 1, p, p, None, p, p, -1, None, 0, 0) == -5
+    assert L.sctl_amd_kernel_matrix_host(99, 0, 1, 1, p, p, None, p, -1, None, 0, 0) == -1
+
+
+def test_no_cpu_fallback_without_device():
+    if sctl_amd.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(api.SctlAmdError, match="no HIP device"):
+        sctl_amd.eval_host("Laplace3D-FxU", np.zeros(3), np.ones(3), None, np.ones(1))
+    with pytest.raises(api.SctlAmdError, match="no HIP device"):
+        sctl_amd.kernel_matrix_host("Laplace3D-FxU", np.zeros(3), np.ones(3), None)
+
+
+def test_launch_planner():
+    """Enough workgroups for 256 CUs at every BASELINE size; source splits only when targets are few."""
+    for name in sctl_amd.KERNEL_NAMES:
+        for real in (0, 1):
+            for N in (1, 300, 1 << 14, 1 << 18, 1 << 20, 1 << 23):
+                p = sctl_amd.plan(name, real, N, N)
+                assert p["trg_per_lane"] in (1, 2, 4) and p["src_splits"] >= 1
+                assert p["workgroups"] >= min(1024, ((N + 255) // 256) * ((N + 255) // 256))
+                k1 = sctl_amd.kernel_info(name)["k1"]
+                assert p["workspace_bytes"] == (0 if p["src_splits"] == 1 else p["src_splits"] * N * k1 * (8 if real == 0 else 4))
+    big = sctl_amd.plan("Laplace3D-FxU", 0, 1 << 20, 1 << 20)
+    assert big["src_splits"] == 1 and big["workspace_bytes"] == 0 and big["trg_per_lane"] == 2
+    small = sctl_amd.plan("Laplace3D-FxU", 0, 1 << 14, 1 << 14)
+    assert small["src_splits"] > 1
+
+
+def test_product_tree_never_touches_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may use oracle/ (the checker is not the product)."""
+    offenders = []
+    for base in ("sctl_amd", "include"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            if "build" in dp.split(os.sep):
+                continue
+            for fn in files:
+                if fn.endswith((".py", ".hpp", ".h", ".hip", ".cpp", "Makefile")):
+                    txt = open(os.path.join(dp, fn), errors="ignore").read()
+                    if re.search(r"^\s*(import|from)\s+oracle\b|libsctl_oracle|sctl_oracle_|oracle/_ref|libsctl_ref", txt, flags=re.M):
+                        offenders.append(os.path.join(dp, fn))
+    assert offenders == []
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    assert bench.count("import oracle") == 1 and "def cpu_baseline" in bench
+
+
+def test_rand48_matches_posix():
+    """Known drand48 values after srand48(7) (checked against glibc when the fixtures were generated)."""
+    from sctl_amd.rand48 import Rand48
+    v = Rand48(7).drand48(3)
+    assert v[0] == 0.2664441967654092 and v[1] == 0.68203523019062118 and v[2] == 0.26549059342699977
+    a = Rand48(3).drand48(20000)          # block jump-ahead path == sequential path
+    g = Rand48(3)
+    b = np.concatenate([g.drand48(100) for _ in range(200)])
+    assert np.array_equal(a, b)
