@@ -97,10 +97,18 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: sctl_amd has no CPU path to measure")
+    # Rehearsal switch for a ONE-GPU box only: all ranks share device 0 and talk over gloo (RCCL refuses two ranks on one
+    # device).  The driver's real multi-GPU runs never set it and use the "nccl" backend (= RCCL over xGMI).
+    rehearsal = os.environ.get("SCTL_AMD_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     kernel, N, dtype, desc = WORKLOADS[args.workload]
     info = sctl_amd.kernel_info(kernel)

@@ -131,6 +131,23 @@ class Reference(_Base):
         assert rc == 0, rc
         return M
 
+    def boundary_far_field(self, name, xt, xn_trg, xs, xn, wts, f, trg_normal_dot_prod=False, tol=1e-10, nodes_per_elem=1, upsample=1):
+        """BoundaryIntegralOp::ComputePotential on a point element list with no near zone == ComputeFarField
+        (boundary_integral.txx:1016-1077).  xt=None: targets are the surface nodes."""
+        inf = self.info(name)
+        Ns = xs.size // 3
+        Nt = 0 if xt is None else xt.size // 3
+        NT = Nt if Nt else Ns
+        k1 = inf["k1"] // 3 if trg_normal_dot_prod else inf["k1"]
+        U = np.zeros(NT * k1, dtype=np.float64)
+        n = C.c_int64()
+        fn = self.lib.sctl_ref_boundary_far_field
+        fn.argtypes = [C.c_char_p, C.c_int64, C.c_int64] + [C.c_void_p] * 6 + [C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int64)]
+        rc = fn(name.encode(), Nt, Ns, _ptr(xt), _ptr(xn_trg), _ptr(xs), _ptr(xn), _ptr(wts), _ptr(f), 1 if trg_normal_dot_prod else 0,
+                tol, nodes_per_elem, upsample, _ptr(U), C.byref(n))
+        assert rc == 0 and n.value == U.size, (rc, n.value, U.size)
+        return U
+
     def particle_fmm_eval_direct(self, name, xt, xs, xn, f, digits=10):
         inf = self.info(name)
         Nt, Ns = xt.size // 3, xs.size // 3
@@ -138,6 +155,20 @@ class Reference(_Base):
         rc = self.lib.sctl_ref_particle_fmm_eval_direct(name.encode(), 0, Nt, Ns, _ptr(xt), _ptr(xs), _ptr(xn), _ptr(f), _ptr(U), digits)
         assert rc == 0, rc
         return U
+
+
+def far_field_restatement(O, name, xt, xn_trg, xs, xn, wts, f, trg_normal_dot_prod=False):
+    """CPU restatement of BoundaryIntegralOp::ComputeFarField (boundary_integral.txx:1016-1077): density x weights,
+    direct sum, optional dot product of the K1/3 x 3 output with the target normals.  xt=None: targets = surface nodes."""
+    inf = O.info(name)
+    Ns = xs.size // 3
+    T, Tn = (xs, xn) if xt is None else (xt, xn_trg)
+    NT = T.size // 3
+    fw = (f.reshape(Ns, inf["k0"]) * wts[:, None]).ravel()
+    u = O.eval(name, T, xs, xn if inf["nd"] else None, fw)
+    if trg_normal_dot_prod:
+        u = (u.reshape(NT, inf["k1"] // 3, 3) * Tn.reshape(NT, 1, 3)).sum(-1).ravel()
+    return u
 
 
 def restatement():

@@ -24,6 +24,28 @@ SIZES = [(1, 1), (7, 5), (64, 64), (257, 1000), (1024, 1024)]
 HELMHOLTZ_K = [7.5, 0.3]
 
 
+# (Nt, Ns, nodes per element, far-field upsampling, dot with target normals, targets = surface nodes)
+FAR_FIELD_CASES = {
+    "Laplace3D-FxU": [(100, 200, 1, 1, 0, False), (100, 203, 4, 2, 0, False), (0, 150, 4, 1, 0, True)],
+    "Laplace3D-DxU": [(77, 203, 5, 1, 0, False)],
+    "Laplace3D-FxdU": [(77, 203, 3, 2, 1, False)],
+    "Stokes3D-DxU": [(77, 203, 5, 1, 0, False), (0, 120, 3, 2, 0, True)],
+    "Stokes3D-FxT": [(50, 100, 3, 1, 1, False)],
+}
+
+
+def far_field_inputs(seed, Nt, Ns, k0):
+    """drand48 draw order shared with tests/cpp/bie_driver.cpp: targets, target normals, nodes, node normals, weights, density."""
+    g = Rand48(seed)
+    xt = g.drand48(Nt * 3) - 0.5
+    xnt = g.drand48(Nt * 3) - 0.5
+    xs = g.drand48(Ns * 3) - 0.5
+    xn = g.drand48(Ns * 3) - 0.5
+    w = g.drand48(Ns) * 0.01
+    f = g.drand48(Ns * k0) - 0.5
+    return xt, xnt, xs, xn, w, f
+
+
 def ctx_for(name):
     return np.array(HELMHOLTZ_K) if name.startswith("Helmholtz") else None
 
@@ -85,6 +107,15 @@ def main():
             xt, xs, xn, f = point_cloud(seed, 500, 500, inf["k0"], inf["nd"], np.float64)
             u = R.particle_fmm_eval_direct(name, xt, xs, xn, f, digits=10)
             add("particle_fmm", "f64_fmm500", u, dtype="f64", Nt=500, Ns=500, seed=seed, digits=10)
+        # BoundaryIntegralOp far field (boundary_integral.txx:1016-1077) through the reference's ComputePotential on a point
+        # element list without a near zone; inputs drawn in the order of far_field_inputs() below
+        for (Nt, Ns, npe, ups, dot, self_trg) in FAR_FIELD_CASES.get(name, []):
+            seed += 1
+            xt, xnt, xs, xn, w, f = far_field_inputs(seed, Nt, Ns, inf["k0"])
+            u = R.boundary_far_field(name, None if self_trg else xt, xnt, xs, xn, w, f, trg_normal_dot_prod=bool(dot), tol=1e-10,
+                                     nodes_per_elem=npe, upsample=ups)
+            add("far_field", "f64_far_%dx%d_e%d_u%d_d%d_s%d" % (Nt, Ns, npe, ups, dot, int(self_trg)), u, dtype="f64", Nt=Nt, Ns=Ns, seed=seed,
+                digits=11, nodes_per_elem=npe, upsample=ups, trg_normal_dot_prod=dot, self_targets=int(self_trg))
         np.savez_compressed(os.path.join(out_dir, name + ".npz"), **arrays)
         print(name, "cases:", len(arrays))
     with open(os.path.join(out_dir, "manifest.json"), "w") as fh:

@@ -57,6 +57,51 @@ struct Helmholtz3D_FxU {    // exp(ikr)/r, complex k = ctx[0] + i ctx[1] (two do
 };
 }  // namespace ref_ext
 
+namespace ref_ext {
+// A minimal element list for driving the reference's BoundaryIntegralOp (include/sctl/boundary_integral.hpp:64-213):
+// `nodes_per_elem` surface nodes per element; the far-field quadrature of an element is its own nodes, each repeated
+// `upsample` times with weight / upsample (GetFarFieldDensity then copies the density to the repeated nodes), and
+// the far-field distance is 0, so that no target is "near" and ComputePotential == ComputeFarField
+// (boundary_integral.txx:608-614, 1016-1077).  MatrixFree() = true skips the self/near operator matrices (:792-797).
+template <class Real> class PointElemList : public sctl::ElementListBase<Real> {
+ public:
+  PointElemList() : npe(1), ups(1) {}
+  PointElemList(const sctl::Vector<Real>& X_, const sctl::Vector<Real>& Xn_, const sctl::Vector<Real>& w_, sctl::Long nodes_per_elem, sctl::Long upsample)
+      : X(X_), Xn(Xn_), w(w_), npe(nodes_per_elem), ups(upsample) {}
+  sctl::Long Size() const override { return (w.Dim() + npe - 1) / npe; }
+  void GetNodeCoord(sctl::Vector<Real>* X_, sctl::Vector<Real>* Xn_, sctl::Vector<sctl::Long>* cnt) const override {
+    if (X_) *X_ = X;
+    if (Xn_) *Xn_ = Xn;
+    if (cnt) { cnt->ReInit(Size()); for (sctl::Long i = 0; i < Size(); i++) (*cnt)[i] = std::min<sctl::Long>(npe, w.Dim() - i * npe); }
+  }
+  void GetFarFieldNodes(sctl::Vector<Real>& X_, sctl::Vector<Real>& Xn_, sctl::Vector<Real>& wts, sctl::Vector<Real>& dist_far,
+                        sctl::Vector<sctl::Long>& cnt, const Real tol) const override {
+    const sctl::Long N = w.Dim();
+    X_.ReInit(N * ups * 3); Xn_.ReInit(N * ups * 3); wts.ReInit(N * ups); dist_far.ReInit(N * ups);
+    for (sctl::Long i = 0; i < N; i++)
+      for (sctl::Long u = 0; u < ups; u++) {
+        for (int k = 0; k < 3; k++) { X_[(i * ups + u) * 3 + k] = X[i * 3 + k]; Xn_[(i * ups + u) * 3 + k] = Xn[i * 3 + k]; }
+        wts[i * ups + u] = w[i] / ups;
+        dist_far[i * ups + u] = 0;
+      }
+    cnt.ReInit(Size());
+    for (sctl::Long i = 0; i < Size(); i++) cnt[i] = std::min<sctl::Long>(npe, N - i * npe) * ups;
+  }
+  void GetFarFieldDensity(sctl::Vector<Real>& Fout, const sctl::Vector<Real>& Fin) const override {
+    if (ups == 1) { if (Fout.Dim()) Fout.ReInit(0); return; }      // "density at far nodes == density at nodes" branch
+    const sctl::Long N = w.Dim(), dof = (N ? Fin.Dim() / N : 0);
+    if (Fout.Dim() != N * ups * dof) Fout.ReInit(N * ups * dof);
+    for (sctl::Long i = 0; i < N; i++)
+      for (sctl::Long u = 0; u < ups; u++)
+        for (sctl::Long k = 0; k < dof; k++) Fout[(i * ups + u) * dof + k] = Fin[i * dof + k];
+  }
+  bool MatrixFree() const override { return true; }
+ private:
+  sctl::Vector<Real> X, Xn, w;
+  sctl::Long npe, ups;
+};
+}  // namespace ref_ext
+
 namespace {
 using namespace sctl;
 
@@ -155,6 +200,33 @@ int sctl_ref_particle_fmm_eval_direct(const char* name, int real, int64_t Nt, in
     Vector<Real> U;
     fmm.EvalDirect(U, "T");
     std::memcpy(v_trg, &U[0], sizeof(Real) * U.Dim());
+    return 0;
+  });
+}
+
+// BoundaryIntegralOp<Real,Kernel>::ComputePotential with the point element list above (no near targets), i.e. the
+// far-field leg: F_far = density * weights, fmm.Eval, optional dot product with the target normals
+// (boundary_integral.txx:1016-1077).  xt == NULL (nt == 0): targets are the surface nodes themselves (:748-756).
+int sctl_ref_boundary_far_field(const char* name, int64_t Nt, int64_t Ns, const double* xt, const double* xn_trg, const double* xs,
+                                const double* xn, const double* wts, const double* f, int trg_normal_dot_prod, double tol,
+                                int nodes_per_elem, int upsample, double* u, int64_t* u_len) {
+  return dispatch(name, [&](auto k) {
+    using K = decltype(k);
+    using Real = double;
+    K ker;
+    BoundaryIntegralOp<Real, K> op(ker, trg_normal_dot_prod != 0, Comm::Self());
+    op.SetAccuracy(tol);
+    Vector<Real> X(Ns * 3, Ptr2Itr<Real>((Real*)xs, Ns * 3), false), Xn(Ns * 3, Ptr2Itr<Real>((Real*)xn, Ns * 3), false);
+    Vector<Real> W(Ns, Ptr2Itr<Real>((Real*)wts, Ns), false), F(Ns * K::SrcDim(), Ptr2Itr<Real>((Real*)f, Ns * K::SrcDim()), false);
+    op.AddElemList(ref_ext::PointElemList<Real>(X, Xn, W, nodes_per_elem, upsample), "points");
+    if (Nt > 0) {
+      op.SetTargetCoord(Vector<Real>(Nt * 3, Ptr2Itr<Real>((Real*)xt, Nt * 3), false));
+      if (trg_normal_dot_prod) op.SetTargetNormal(Vector<Real>(Nt * 3, Ptr2Itr<Real>((Real*)xn_trg, Nt * 3), false));
+    }
+    Vector<Real> U;
+    op.ComputePotential(U, F);
+    *u_len = U.Dim();
+    std::memcpy(u, &U[0], sizeof(Real) * U.Dim());
     return 0;
   });
 }

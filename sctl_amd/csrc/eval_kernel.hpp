@@ -13,6 +13,8 @@
 // so there is no double buffering of the tile: the tile fill is < 1 % of the tile's compute and other
 // resident workgroups cover it.
 #pragma once
+#include <type_traits>
+
 #include "ukernels.hpp"
 
 namespace sctl_amd {
@@ -37,16 +39,22 @@ template <class R> struct VecOf;
 template <> struct VecOf<double> { typedef double type __attribute__((ext_vector_type(2))); static constexpr int N = 2; };
 template <> struct VecOf<float> { typedef float type __attribute__((ext_vector_type(4))); static constexpr int N = 4; };
 
-// TWO_LEVEL: keep a per-tile accumulator and add it to the running sum once per tile (pairwise-style
-// summation; bounds fp32 error growth at Ns = 2^23, SURVEY.md §7 "fp32 at N=8M").
-template <class Ker, class R, int MODE, int T, bool TWO_LEVEL>
+// sources per unrolled loop body: 4-8 independent accumulation chains in flight per lane
+template <int T, int K1> struct UnrollOf { static constexpr int value = (T * K1 >= 8) ? 1 : ((T * K1 >= 3) ? 2 : 4); };
+
+template <class R> __device__ __forceinline__ R max_finite();
+template <> __device__ __forceinline__ double max_finite<double>() { return 1.7976931348623157e308; }
+template <> __device__ __forceinline__ float max_finite<float>() { return 3.402823466e38f; }
+__device__ __forceinline__ double fabs_(double x) { return __builtin_fabs(x); }
+__device__ __forceinline__ float fabs_(float x) { return __builtin_fabsf(x); }
+
+template <class Ker, class R, int MODE, int T>
 __global__ void __launch_bounds__(kBlock) eval_kernel(const EvalArgs<R> a) {
   constexpr int K0 = Ker::K0, K1 = Ker::K1, ND = Ker::ND, NREC = Ker::NREC;
   using V = typename VecOf<R>::type;
   constexpr int VN = VecOf<R>::N;
   constexpr int NV = (NREC + VN - 1) / VN;     // 16-byte LDS words per record
   constexpr int NRECP = NV * VN;               // record padded to whole words (fp32: multiples of 4 reals)
-  constexpr int UNROLL = (T >= 4 || K1 > 4) ? 1 : (T == 2 ? 2 : 4);   // ~4 independent pair chains in flight
   __shared__ V tile[kTile * NV];
 
   const int tid = threadIdx.x;
@@ -68,6 +76,8 @@ __global__ void __launch_bounds__(kBlock) eval_kernel(const EvalArgs<R> a) {
   const int64_t s_end = (s_begin + a.chunk < a.Ns) ? s_begin + a.chunk : a.Ns;
   const int64_t len = (s_end > s_begin) ? s_end - s_begin : 0;
   const int ntile = (int)((len + kTile - 1) / kTile);
+  bool always_masked = (ntile < 4);   // few tiles: speculation cannot pay for a repair
+  int repairs = 0;
 
   for (int it = 0; it < ntile; it++) {
     const int64_t s0 = s_begin + (int64_t)it * kTile;
@@ -93,42 +103,57 @@ __global__ void __launch_bounds__(kBlock) eval_kernel(const EvalArgs<R> a) {
     }
     __syncthreads();
 
-    R tacc[T][K1];   // dead (removed by the compiler) unless TWO_LEVEL
-    if constexpr (TWO_LEVEL) {
+    // Per-tile accumulators (folded into the running sums once per tile: two-level summation, which also bounds
+    // fp32 error growth at Ns = 2^23).  The tile is first evaluated WITHOUT the r = 0 mask; a
+    // coincident pair poisons the tile sums with inf/NaN, in which case the whole wave re-runs this tile masked.
+    // A wave that had to repair more than 1/8 of its tiles (e.g. targets == sources in shuffled order at small N)
+    // stops speculating and runs masked from then on.
+    R tacc[T][K1];
+    auto run_tile = [&](auto masked_tag) {
+      constexpr bool MASKED = decltype(masked_tag)::value;
 #pragma unroll
       for (int j = 0; j < T; j++)
 #pragma unroll
         for (int k = 0; k < K1; k++) tacc[j][k] = 0;
-    }
-    // one source against the T targets of this lane; the record is read at ONE LDS address by the whole
-    // wave (broadcast) and kept in registers for the T pair evaluations
-    auto one_source = [&](int s) {
-      R rec[NRECP];
+      // one source against the T targets of this lane; the record is read at ONE LDS address by the whole wave
+      // (broadcast) and kept in registers for the T pair evaluations
+      auto one_source = [&](int s) {
+        R rec[NRECP];
 #pragma unroll
-      for (int v = 0; v < NV; v++) {
-        const V w = tile[s * NV + v];
+        for (int v = 0; v < NV; v++) {
+          const V w = tile[s * NV + v];
 #pragma unroll
-        for (int e = 0; e < VN; e++) rec[v * VN + e] = w[e];
-      }
+          for (int e = 0; e < VN; e++) rec[v * VN + e] = w[e];
+        }
 #pragma unroll
-      for (int j = 0; j < T; j++) {
-        const R d[3] = {xt[j][0] - rec[0], xt[j][1] - rec[1], xt[j][2] - rec[2]};
-        if constexpr (TWO_LEVEL) Ker::template pair<R, MODE>(tacc[j], d, rec, a.ctx, K);
-        else Ker::template pair<R, MODE>(acc[j], d, rec, a.ctx, K);
+        for (int j = 0; j < T; j++) {
+          const R d[3] = {xt[j][0] - rec[0], xt[j][1] - rec[1], xt[j][2] - rec[2]};
+          Ker::template pair<R, MODE, MASKED>(tacc[j], d, rec, a.ctx, K);
+        }
+      };
+      if (ns == kTile) {   // every tile but possibly the last: constant trip count, unrolled
+#pragma unroll UnrollOf<T, Ker::K1>::value
+        for (int s = 0; s < kTile; s++) one_source(s);
+      } else {
+        for (int s = 0; s < ns; s++) one_source(s);
       }
     };
-    if (ns == kTile) {   // every tile but possibly the last: constant trip count, unrolled
-#pragma unroll UNROLL
-      for (int s = 0; s < kTile; s++) one_source(s);
-    } else {
-      for (int s = 0; s < ns; s++) one_source(s);
-    }
-    if constexpr (TWO_LEVEL) {
+    bool repaired = true;
+    if (!always_masked) {
+      run_tile(std::false_type());
+      bool bad = false;
 #pragma unroll
       for (int j = 0; j < T; j++)
 #pragma unroll
-        for (int k = 0; k < K1; k++) acc[j][k] += tacc[j][k];
+        for (int k = 0; k < K1; k++) bad |= !(fabs_(tacc[j][k]) <= max_finite<R>());
+      repaired = __any(bad);                 // wave-uniform
+      if (repaired && (++repairs) * 8 > ntile) always_masked = true;
     }
+    if (repaired) run_tile(std::true_type());
+#pragma unroll
+    for (int j = 0; j < T; j++)
+#pragma unroll
+      for (int k = 0; k < K1; k++) acc[j][k] += tacc[j][k];
   }
 
 #pragma unroll
@@ -181,7 +206,7 @@ __global__ void __launch_bounds__(kBlock) matrix_kernel(int64_t Nt, int64_t Ns, 
 #pragma unroll
     for (int k = 0; k < K1; k++) acc[k] = 0;
     Ker::template pack<R>(rec, x, n, f);
-    Ker::template pair<R, MODE>(acc, d, rec, ctx, K);
+    Ker::template pair<R, MODE, true>(acc, d, rec, ctx, K);
     R* row = M + ((s * K0 + k0) * Nt + t) * K1;
 #pragma unroll
     for (int k = 0; k < K1; k++) row[k] = acc[k] * scale;

@@ -23,8 +23,7 @@ struct KernelEntry {
 };
 
 template <class Ker, class R, int MODE, int T> void launch_eval(const EvalArgs<R>& a, dim3 grid, hipStream_t st) {
-  constexpr bool two_level = sizeof(R) == 4;
-  hipLaunchKernelGGL((eval_kernel<Ker, R, MODE, T, two_level>), grid, dim3(kBlock), 0, st, a);
+  hipLaunchKernelGGL((eval_kernel<Ker, R, MODE, T>), grid, dim3(kBlock), 0, st, a);
 }
 template <class Ker, class R, int MODE> void launch_matrix(int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* xn, R* M, R scale,
                                                            const KerCtx& ctx, dim3 grid, hipStream_t st) {

@@ -12,7 +12,7 @@
 //   NREC                reals per packed source record in LDS (multiple of 16 bytes for R = double and float)
 //   FLOPS, scale()      kernel_functions.hpp FLOPS() / uKerScaleFactor
 //   pack(rec, x, n, f)  build the LDS record of one source from the AoS inputs
-//   pair<R,MODE>(acc, d, rec, ctx, K)   one pair interaction, d = x_trg - x_src  (generic-kernel.txx:83)
+//   pair<R,MODE,MASKED>(acc, d, rec, ctx, K)   one pair interaction, d = x_trg - x_src  (generic-kernel.txx:83)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -34,6 +34,9 @@ struct KerCtx { double v[4]; };
 //   MODE 1: one Newton step,  y + y e / 2            (error 3/8 e^2 ~ 1e-15, >= 14 digits)
 //   MODE 2: one Halley step,  y + y e (1/2 + 3/8 e)  (error O(e^3): rounding only)
 // With y = 0 every refinement returns 0, so the mask survives; NaN/inf inputs propagate as in the reference.
+// MASKED = false skips the two mask instructions (9.5 % of the Laplace kernel's time, tools/ubench/laplace_variants):
+// a coincident pair then yields inf/NaN, which eval_kernel.hpp detects per LDS tile and repairs by re-running that
+// tile with MASKED = true — the result is identical to the always-masked evaluation.
 // The one constant that is not a hardware inline constant (3/8) lives in a VGPR pair for the whole kernel
 // (RsqConst, made opaque to the optimiser so that it is not re-materialised with v_mov per use).
 template <class R> struct RsqConst {
@@ -41,8 +44,9 @@ template <class R> struct RsqConst {
   __device__ __forceinline__ RsqConst() : c38(R(0.375)) { asm volatile("" : "+v"(c38)); }
 };
 
-template <int MODE> __device__ __forceinline__ double rsqrt_masked(double r2, const RsqConst<double>& K) {
+template <int MODE, bool MASKED> __device__ __forceinline__ double rsqrt_masked(double r2, const RsqConst<double>& K) {
   double y = __builtin_amdgcn_rsq(r2);
+  if (MASKED) {
   // r2 == 0 -> y = +inf = {hi 0x7ff00000, lo 0} -> 0: one 32-bit compare + one v_cndmask on the high word.
   // The empty asm only stops the optimiser from widening this into a 64-bit compare; the compare and select
   // themselves are compiler-generated so that the gfx950 trans->VALU hazard after v_rsq_f64 is padded correctly
@@ -51,6 +55,7 @@ template <int MODE> __device__ __forceinline__ double rsqrt_masked(double r2, co
   asm("" : "+v"(hi));
   hi = (hi == 0x7ff00000) ? 0 : hi;
   y = __hiloint2double(hi, __double2loint(y));
+  }
   if (MODE >= 1) {
     const double a = r2 * y;
     const double e = __builtin_fma(-a, y, 1.0);
@@ -60,9 +65,9 @@ template <int MODE> __device__ __forceinline__ double rsqrt_masked(double r2, co
   }
   return y;
 }
-template <int MODE> __device__ __forceinline__ float rsqrt_masked(float r2, const RsqConst<float>&) {
+template <int MODE, bool MASKED> __device__ __forceinline__ float rsqrt_masked(float r2, const RsqConst<float>&) {
   float y = __builtin_amdgcn_rsqf(r2);
-  y = (__float_as_uint(y) == 0x7f800000u) ? 0.0f : y;   // r2 == 0 -> +inf -> 0
+  if (MASKED) y = (__float_as_uint(y) == 0x7f800000u) ? 0.0f : y;   // r2 == 0 -> +inf -> 0
   if (MODE >= 1) {   // one Newton step in fp32 (only when more than 7 digits are asked of fp32)
     const float a = r2 * y;
     const float e = __builtin_fmaf(-a, y, 1.0f);
@@ -86,8 +91,8 @@ struct Laplace3D_FxU {
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0];
   }
-  template <class R, int MODE> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const RsqConst<R>& K) {
-    const R rinv = rsqrt_masked<MODE>(len2(d), K);
+  template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const RsqConst<R>& K) {
+    const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K);
     acc[0] = fma_(rec[3], rinv, acc[0]);
   }
 };
@@ -100,8 +105,8 @@ struct Laplace3D_DxU {
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R* n, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = n[0] * f[0]; rec[4] = n[1] * f[0]; rec[5] = n[2] * f[0];
   }
-  template <class R, int MODE> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const RsqConst<R>& K) {
-    const R rinv = rsqrt_masked<MODE>(len2(d), K);
+  template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const RsqConst<R>& K) {
+    const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K);
     const R rinv3 = rinv * rinv * rinv;
     acc[0] = fma_(dot3(d, rec + 3), rinv3, acc[0]);
   }
@@ -115,8 +120,8 @@ struct Laplace3D_FxdU {
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0];
   }
-  template <class R, int MODE> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const RsqConst<R>& K) {
-    const R rinv = rsqrt_masked<MODE>(len2(d), K);
+  template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const RsqConst<R>& K) {
+    const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K);
     const R t = rinv * rinv * rinv * rec[3];
     for (int j = 0; j < 3; j++) acc[j] = fma_(t, d[j], acc[j]);
   }
@@ -130,8 +135,8 @@ struct Stokes3D_FxU {
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0]; rec[4] = f[1]; rec[5] = f[2];
   }
-  template <class R, int MODE> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const RsqConst<R>& K) {
-    const R rinv = rsqrt_masked<MODE>(len2(d), K);
+  template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const RsqConst<R>& K) {
+    const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K);
     const R t = dot3(d, rec + 3) * (rinv * rinv * rinv);
     for (int j = 0; j < 3; j++) acc[j] = fma_(t, d[j], fma_(rinv, rec[3 + j], acc[j]));
   }
@@ -146,8 +151,8 @@ struct Stokes3D_DxU {
     for (int k = 0; k < 3; k++) { rec[k] = x[k]; rec[3 + k] = n[k]; rec[6 + k] = f[k]; }
     rec[9] = 0;
   }
-  template <class R, int MODE> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const RsqConst<R>& K) {
-    const R rinv = rsqrt_masked<MODE>(len2(d), K);
+  template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const RsqConst<R>& K) {
+    const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K);
     const R rinv2 = rinv * rinv;
     const R t = dot3(d, rec + 3) * dot3(d, rec + 6) * (rinv2 * rinv2 * rinv);
     for (int j = 0; j < 3; j++) acc[j] = fma_(t, d[j], acc[j]);
@@ -162,8 +167,8 @@ struct Stokes3D_FxT {
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0]; rec[4] = f[1]; rec[5] = f[2];
   }
-  template <class R, int MODE> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const RsqConst<R>& K) {
-    const R rinv = rsqrt_masked<MODE>(len2(d), K);
+  template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const RsqConst<R>& K) {
+    const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K);
     const R rinv2 = rinv * rinv;
     const R t = dot3(d, rec + 3) * (rinv2 * rinv2 * rinv);
     for (int j = 0; j < 3; j++) {
@@ -181,8 +186,8 @@ struct Stokes3D_FSxU {
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0]; rec[4] = f[1]; rec[5] = f[2]; rec[6] = f[3]; rec[7] = 0;
   }
-  template <class R, int MODE> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const RsqConst<R>& K) {
-    const R rinv = rsqrt_masked<MODE>(len2(d), K);
+  template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const RsqConst<R>& K) {
+    const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K);
     const R t = (dot3(d, rec + 3) + rec[6]) * (rinv * rinv * rinv);
     for (int j = 0; j < 3; j++) acc[j] = fma_(t, d[j], fma_(rinv, rec[3 + j], acc[j]));
   }
@@ -196,8 +201,8 @@ struct Stokes3D_FxUP {
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0]; rec[4] = f[1]; rec[5] = f[2];
   }
-  template <class R, int MODE> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const RsqConst<R>& K) {
-    const R rinv = rsqrt_masked<MODE>(len2(d), K);
+  template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const RsqConst<R>& K) {
+    const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K);
     const R t = dot3(d, rec + 3) * (rinv * rinv * rinv);
     for (int j = 0; j < 3; j++) acc[j] = fma_(t, d[j], fma_(rinv, rec[3 + j], acc[j]));
     acc[3] += t;
@@ -215,8 +220,8 @@ struct Laplace3D_FDxUdU {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2];
     rec[3] = n[0] * f[1]; rec[4] = n[1] * f[1]; rec[5] = n[2] * f[1]; rec[6] = f[0]; rec[7] = 0;
   }
-  template <class R, int MODE> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const RsqConst<R>& K) {
-    const R rinv = rsqrt_masked<MODE>(len2(d), K);
+  template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const RsqConst<R>& K) {
+    const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K);
     const R rinv2 = rinv * rinv;
     const R rinv3 = rinv2 * rinv;
     const R a = dot3(d, rec + 3) * rinv3;               // mu (r.n) / r^3
@@ -235,9 +240,9 @@ struct Helmholtz3D_FxU {
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0]; rec[4] = f[1]; rec[5] = 0;
   }
-  template <class R, int MODE> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx& ctx, const RsqConst<R>& K) {
+  template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx& ctx, const RsqConst<R>& K) {
     const R r2 = len2(d);
-    const R rinv = rsqrt_masked<MODE>(r2, K);
+    const R rinv = rsqrt_masked<MODE, MASKED>(r2, K);
     const R r = r2 * rinv;
     R sn, cs;
     sincos_(R(ctx.v[0]) * r, sn, cs);
