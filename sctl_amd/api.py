@@ -23,7 +23,7 @@ KERNEL_NAMES = ["Laplace3D-FxU", "Laplace3D-DxU", "Laplace3D-FxdU", "Stokes3D-Fx
 SYMBOLS = ["sctl_amd_version", "sctl_amd_last_error", "sctl_amd_device_count", "sctl_amd_kernel_id", "sctl_amd_kernel_name",
            "sctl_amd_kernel_info", "sctl_amd_flops_per_pair", "sctl_amd_eval_device", "sctl_amd_eval_host", "sctl_amd_eval_host_multi",
            "sctl_amd_kernel_matrix_device", "sctl_amd_kernel_matrix_host", "sctl_amd_counters", "sctl_amd_reset_counters",
-           "sctl_amd_eval_plan"]
+           "sctl_amd_eval_plan", "sctl_amd_eval_path"]
 
 
 class SctlAmdError(RuntimeError):
@@ -31,7 +31,8 @@ class SctlAmdError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, "libsctl_amd.so")
+    # SCTL_AMD_LIB: explicit path of another build of the same library (kernel experiments under tools/)
+    return os.environ.get("SCTL_AMD_LIB") or os.path.join(_HERE, "libsctl_amd.so")
 
 
 def lib():
@@ -58,6 +59,7 @@ def lib():
     L.sctl_amd_counters.restype = None
     L.sctl_amd_reset_counters.restype = None
     L.sctl_amd_eval_plan.argtypes = [ci, ci, i64, i64, ci, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(i64), C.POINTER(i64)]
+    L.sctl_amd_eval_path.argtypes = [ci, ci, i64, i64]
     _LIB = L
     return L
 
@@ -100,7 +102,9 @@ def plan(name, real, Nt, Ns, digits=-1):
     t, s = C.c_int(), C.c_int()
     wg, ws = C.c_int64(), C.c_int64()
     _check(lib().sctl_amd_eval_plan(kernel_id(name), real, Nt, Ns, digits, C.byref(t), C.byref(s), C.byref(wg), C.byref(ws)), "eval_plan")
-    return dict(trg_per_lane=t.value, src_splits=s.value, workgroups=wg.value, workspace_bytes=ws.value)
+    path = lib().sctl_amd_eval_path(kernel_id(name), real, Nt, Ns)
+    return dict(trg_per_lane=t.value, src_splits=s.value, workgroups=wg.value, workspace_bytes=ws.value,
+                path="tile-centred" if path == 1 else "exact")
 
 
 def counters():

@@ -1,0 +1,107 @@
+// Host driver of the tile-centred Laplace single-layer path (centered_kernel.hpp): Morton-sort the targets on the device
+// (rocPRIM radix sort of 63-bit keys), evaluate on the sorted order, scatter-add the result back.  Everything is enqueued
+// on the caller's stream; temporaries come from hipMallocAsync and are released with hipFreeAsync.
+#include "centered_kernel.hpp"
+#include "launch.hpp"
+
+#include <cstdlib>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+namespace sctl_amd {
+
+#define CENTERED_TRY(expr)            \
+  do {                                \
+    hipError_t e_ = (expr);           \
+    if (e_ != hipSuccess) return e_;  \
+  } while (0)
+
+namespace {
+struct AsyncBuf {
+  void* p = nullptr;
+  hipStream_t st;
+  explicit AsyncBuf(hipStream_t s) : st(s) {}
+  ~AsyncBuf() { if (p) (void)hipFreeAsync(p, st); }
+  hipError_t alloc(size_t bytes) { return hipMallocAsync(&p, bytes ? bytes : 8, st); }
+};
+
+template <int MODE> void launch_centered(const EvalArgs<double>& a, int T, dim3 grid, hipStream_t st) {
+  static const int variant = [] { const char* e = std::getenv("SCTL_AMD_EXPERIMENT_VARIANT"); return e ? std::atoi(e) : 0; }();   // timing experiments
+  if (T == 1) hipLaunchKernelGGL((laplace_fxu_centered_kernel<MODE, 1>), grid, dim3(kWaveBlock), 0, st, a);
+  else if (variant == 1) hipLaunchKernelGGL((laplace_fxu_centered_kernel<MODE, 2, 2, 1>), grid, dim3(kWaveBlock), 0, st, a);
+  else if (variant == 2) hipLaunchKernelGGL((laplace_fxu_centered_kernel<MODE, 2, 4, 6>), grid, dim3(kWaveBlock), 0, st, a);
+  else if (variant == 3) hipLaunchKernelGGL((laplace_fxu_centered_kernel<MODE, 2, 2, 8>), grid, dim3(kWaveBlock), 0, st, a);
+  else hipLaunchKernelGGL((laplace_fxu_centered_kernel<MODE, 2>), grid, dim3(kWaveBlock), 0, st, a);
+}
+}  // namespace
+
+// v_trg[Nt] += scale * sum_s f_s / |x_t - x_s|  (Laplace3D-FxU, fp64), mode = rsqrt refinement (ukernels.hpp)
+// Launch geometry of the centred kernel: one wave per workgroup, 64*T targets each.  The kernel holds 103 VGPRs, so 16
+// waves are resident per CU; the work per wave varies with its share of near sources (0.5 % .. 34 % at 2^20 uniform
+// points), so the source range is split until there are >= 32 "rounds" of workgroups — measured on 2^20 x 2^20:
+// 1 split 517 ms, 4 splits 480 ms, 16 splits 469 ms (exact kernel on the same GPU: 520 ms).
+void centered_plan(int64_t Nt, int64_t Ns, int cus, int* T, int* splits, int64_t* chunk) {
+  *T = 2;
+  const int64_t wg_x = (Nt + kWaveBlock * 2 - 1) / (kWaveBlock * 2);
+  const int64_t want = (int64_t)cus * 16 * 32;
+  const int64_t ntile = (Ns + kWaveTile - 1) / kWaveTile;
+  int64_t s = (want + wg_x - 1) / wg_x;
+  if (const char* e = std::getenv("SCTL_AMD_EXPERIMENT_SPLITS")) s = std::atoi(e);   // timing experiments only
+  if (s > ntile / 64) s = ntile / 64;      // at least 64 tiles (4096 sources) per split
+  if (s > 64) s = 64;
+  if (s < 1) s = 1;
+  const int64_t tiles_per = (ntile + s - 1) / s;
+  *chunk = tiles_per * kWaveTile;
+  *splits = (int)((Ns + *chunk - 1) / *chunk);
+}
+
+hipError_t eval_laplace_fxu_centered(int64_t Nt, int64_t Ns, const double* xt, const double* xs, const double* f, double* v_trg, double scale,
+                                     int mode, int cus, hipStream_t st) {
+  int T, splits;
+  int64_t chunk;
+  centered_plan(Nt, Ns, cus, &T, &splits, &chunk);
+  const int nblk_box = 256;
+  AsyncBuf part(st), keys(st), keys2(st), idx(st), idx2(st), xts(st), outs(st), tmp(st), partial(st);
+  CENTERED_TRY(part.alloc(sizeof(double) * 6 * nblk_box));
+  CENTERED_TRY(keys.alloc(sizeof(uint64_t) * Nt));
+  CENTERED_TRY(keys2.alloc(sizeof(uint64_t) * Nt));
+  CENTERED_TRY(idx.alloc(sizeof(uint32_t) * Nt));
+  CENTERED_TRY(idx2.alloc(sizeof(uint32_t) * Nt));
+  CENTERED_TRY(xts.alloc(sizeof(double) * 3 * Nt));
+  CENTERED_TRY(outs.alloc(sizeof(double) * Nt));
+  const unsigned nb = (unsigned)((Nt + kBlock - 1) / kBlock);
+
+  hipLaunchKernelGGL((bbox_partial_kernel<double>), dim3(nblk_box), dim3(kBlock), 0, st, xt, Nt, (double*)part.p);
+  hipLaunchKernelGGL((morton_keys_kernel<double>), dim3(nb), dim3(kBlock), 0, st, xt, Nt, (const double*)part.p, nblk_box, (uint64_t*)keys.p,
+                     (uint32_t*)idx.p);
+  size_t tmp_bytes = 0;
+  CENTERED_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (uint64_t*)keys.p, (uint64_t*)keys2.p, (uint32_t*)idx.p, (uint32_t*)idx2.p, (size_t)Nt, 0,
+                                         63, st));
+  CENTERED_TRY(tmp.alloc(tmp_bytes));
+  CENTERED_TRY(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, (uint64_t*)keys.p, (uint64_t*)keys2.p, (uint32_t*)idx.p, (uint32_t*)idx2.p, (size_t)Nt, 0, 63,
+                                         st));
+  const uint32_t* perm = (const uint32_t*)idx2.p;
+  hipLaunchKernelGGL((gather_points_kernel<double>), dim3(nb), dim3(kBlock), 0, st, xt, perm, Nt, (double*)xts.p);
+  CENTERED_TRY(hipMemsetAsync(outs.p, 0, sizeof(double) * Nt, st));
+
+  EvalArgs<double> a{};
+  a.Nt = Nt; a.Ns = Ns; a.xt = (const double*)xts.p; a.xs = xs; a.xn = nullptr; a.f = f; a.v_trg = (double*)outs.p; a.partial = nullptr;
+  a.chunk = chunk; a.scale = scale;
+  a.ctx.v[0] = kNearFactor2;
+  if (const char* e = std::getenv("SCTL_AMD_EXPERIMENT_NEAR_FACTOR")) a.ctx.v[0] = std::atof(e);   // timing experiments only
+  if (splits > 1) {
+    CENTERED_TRY(partial.alloc(sizeof(double) * (size_t)splits * Nt));
+    a.partial = (double*)partial.p;
+  }
+  const dim3 grid((unsigned)((Nt + (int64_t)kWaveBlock * T - 1) / ((int64_t)kWaveBlock * T)), (unsigned)splits);
+  if (mode == 0) launch_centered<0>(a, T, grid, st);
+  else if (mode == 1) launch_centered<1>(a, T, grid, st);
+  else launch_centered<2>(a, T, grid, st);
+  CENTERED_TRY(hipGetLastError());
+  if (splits > 1)
+    hipLaunchKernelGGL((reduce_splits_kernel<double>), dim3(nb), dim3(kBlock), 0, st, (double*)outs.p, (const double*)a.partial, Nt, splits, scale);
+  hipLaunchKernelGGL((scatter_add_kernel<double>), dim3(nb), dim3(kBlock), 0, st, (const double*)outs.p, perm, Nt, 1, v_trg);
+  return hipGetLastError();
+}
+
+}  // namespace sctl_amd

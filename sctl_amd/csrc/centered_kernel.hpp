@@ -1,0 +1,275 @@
+// Laplace single-layer evaluation with tile-centred distances: the fast path of the headline kernel.
+//
+// Why: the exact kernel (eval_kernel.hpp) is at the fp64 issue limit of its instruction mix — 12 fp64 ops + v_rsq_f64
+// per pair; fp64 MFMA shares the fp64 pipe on gfx950 (tools/ubench/mfma_mix.hip), so the only lever
+// left is fewer instructions.  Six of the twelve are geometry: d = x_t - x_s (3) and r2 = |d|^2 (3).  With coordinates
+// taken relative to a centre c close to the workgroup's targets,
+//     r2 = (|x_t'|^2 + |x_s'|^2) - 2 x_t'.x_s'       x' = x - c
+// is 1 add + 3 FMAs (|x_t'|^2 and -2 x_t' live in registers, x_s' and |x_s'|^2 in LDS), i.e. four instructions instead
+// of six, and it is ACCURATE whenever the source is far from the target cluster: for |x_s'|^2 > 9 Rt^2 (Rt = radius of
+// the workgroup's targets about c) the rounding error of r2 is <= 14.5 u relative (u = 2^-53), typically ~4 u — the
+// same size as the error of the exact path (d rounded, then three roundings).  Sources that are NOT far
+// (|x_s'|^2 <= 9 Rt^2, a few per cent when the targets of a workgroup are spatially compact) take the reference-exact
+// path d = x_t - x_s with the r = 0 mask; coincident pairs can only occur there, so the far loop needs no mask at all.
+//
+// The far/near decision is per (wave, source) — uniform across the wave — and is made when a tile of 64 sources is staged
+// into LDS: far and near sources are compacted into two record lists, so both inner loops have uniform trip counts and
+// no per-pair branch.  The host side (centered.hip) Morton-sorts the targets first so that the 128 targets of a wave are
+// compact; results are scattered back through the permutation.
+#pragma once
+#include "eval_kernel.hpp"
+
+namespace sctl_amd {
+
+constexpr double kNearFactor2 = 9.0;   // near  <=>  |x_s - c|^2 <= kNearFactor2 * Rt^2
+
+template <class R> __device__ __forceinline__ R wave_min(R v) {
+  for (int o = 32; o > 0; o >>= 1) { const R w = __shfl_xor(v, o); v = (w < v) ? w : v; }
+  return v;
+}
+template <class R> __device__ __forceinline__ R wave_max(R v) {
+  for (int o = 32; o > 0; o >>= 1) { const R w = __shfl_xor(v, o); v = (w > v) ? w : v; }
+  return v;
+}
+
+// One wave64 per workgroup: the unit that shares a centre is 64*T Morton-consecutive targets (128 for T = 2), which keeps
+// the cluster radius — and with it the fraction of near sources (3.5 % at 2^20 uniform points, vs 9 % for 512 targets) —
+// small and evens out the work per SIMD (32 independent workgroups per CU).  Each wave stages its own 64-source tiles;
+// the 4x larger L2 read volume (every wave streams all sources: 0.6 TB/s at 2^20) is far below the L2's bandwidth.
+constexpr int kWaveBlock = 64;   // lanes per workgroup of the centred kernel
+constexpr int kWaveTile = 64;    // sources per LDS tile
+constexpr int kNearCap = 128;    // capacity of the per-wave list of pending near sources
+
+// a.xt: Morton-sorted targets; a.v_trg / a.partial: indexed like a.xt (the caller scatters back); fp64 only.
+template <int MODE, int T, int UNR = 4, int MINW = 1>
+__global__ void __launch_bounds__(kWaveBlock, MINW) laplace_fxu_centered_kernel(const EvalArgs<double> a) {
+  using R = double;
+  typedef double V __attribute__((ext_vector_type(2)));
+  using Ker = Laplace3D_FxU;
+  __shared__ V farB[(kWaveTile + 4) * 2];    // {x', y'}, {z', |x_s'|^2}   (+ padding records)
+  __shared__ R farF[kWaveTile + 4];          // density
+  __shared__ V nearA[(kNearCap + 2) * 2];    // {x, y}, {z, f}  original coordinates; near sources are collected over
+                                             // several tiles and evaluated in batches, so the exact loop runs rarely
+                                             // and with a long trip count
+
+  const int lane = threadIdx.x;
+  const int64_t tbase = (int64_t)blockIdx.x * (kWaveBlock * T);
+  const typename Ker::template Consts<R> K;
+
+  // ---- targets of this lane, cluster centre (bounding-box midpoint) and radius --------------------------------
+  R xt[T][3];
+  R c[3];
+  {
+    R lo[3] = {1.7976931348623157e308, 1.7976931348623157e308, 1.7976931348623157e308}, hi[3] = {-lo[0], -lo[0], -lo[0]};
+#pragma unroll
+    for (int j = 0; j < T; j++) {
+      int64_t t = tbase + j * kWaveBlock + lane;
+      if (t >= a.Nt) t = a.Nt - 1;   // tail lanes repeat the last target; never stored
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        xt[j][k] = a.xt[t * 3 + k];
+        lo[k] = (xt[j][k] < lo[k]) ? xt[j][k] : lo[k];
+        hi[k] = (xt[j][k] > hi[k]) ? xt[j][k] : hi[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) c[k] = 0.5 * wave_min(lo[k]) + 0.5 * wave_max(hi[k]);
+  }
+  R m2x[T][3], tt[T], rt2 = 0;
+#pragma unroll
+  for (int j = 0; j < T; j++) {
+    const R p[3] = {xt[j][0] - c[0], xt[j][1] - c[1], xt[j][2] - c[2]};
+    tt[j] = len2(p);
+    rt2 = (tt[j] > rt2) ? tt[j] : rt2;
+#pragma unroll
+    for (int k = 0; k < 3; k++) m2x[j][k] = -2.0 * p[k];
+  }
+  rt2 = wave_max(rt2);
+  const R near_r2 = a.ctx.v[0] * rt2;   // ctx.v[0] = kNearFactor2; NaN coordinates fail every comparison => "near" => exact path
+
+  R acc[T];
+#pragma unroll
+  for (int j = 0; j < T; j++) acc[j] = 0;
+
+  const int64_t s_begin = (int64_t)blockIdx.y * a.chunk;
+  const int64_t s_end = (s_begin + a.chunk < a.Ns) ? s_begin + a.chunk : a.Ns;
+  const int64_t len = (s_end > s_begin) ? s_end - s_begin : 0;
+  const int ntile = (int)((len + kWaveTile - 1) / kWaveTile);
+
+  // software pipeline: the next tile's source is loaded into registers while the current tile is evaluated
+  R x[3] = {0, 0, 0}, f = 0;
+  auto load_source = [&](int it) {
+    const int64_t s = s_begin + (int64_t)it * kWaveTile + lane;
+    if (s < s_end) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) x[k] = a.xs[s * 3 + k];
+      f = a.f[s];
+    }
+  };
+  if (ntile > 0) load_source(0);
+
+  // ---- near sources: the reference-exact pair (d = x_t - x_s, masked at r = 0), evaluated in batches -----------
+  const R far_off = 1.0e3 * (1.0 + __builtin_sqrt(rt2));
+  int nn = 0;   // pending near sources in nearA (wave-uniform)
+  auto flush_near = [&]() {
+    if (nn & 1) {   // pad to an even count with a null source
+      if (lane == 0) { nearA[nn * 2] = V{c[0] + far_off, c[1]}; nearA[nn * 2 + 1] = V{c[2], 0.0}; }
+      __syncthreads();
+    }
+    for (int s = 0; s < nn; s += 2) {
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const V a0 = nearA[(s + u) * 2], a1 = nearA[(s + u) * 2 + 1];
+#pragma unroll
+        for (int j = 0; j < T; j++) {
+          const R d[3] = {xt[j][0] - a0[0], xt[j][1] - a0[1], xt[j][2] - a1[0]};
+          acc[j] = fma_(a1[1], rsqrt_masked<MODE, true>(len2(d), K.rsq), acc[j]);
+        }
+      }
+    }
+    nn = 0;
+  };
+
+  for (int it = 0; it < ntile; it++) {
+    const int ns = (it == ntile - 1) ? (int)(len - (int64_t)it * kWaveTile) : kWaveTile;
+    // ---- stage one tile: classify each source as far / near and compact the two lists --------------------
+    const bool valid = lane < ns;
+    const R p[3] = {x[0] - c[0], x[1] - c[1], x[2] - c[2]};
+    const R ss = len2(p);
+    const bool is_far = valid && (ss > near_r2);
+    const bool is_near = valid && !is_far;
+    const unsigned long long bf = __ballot(is_far), bn = __ballot(is_near);
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int nfar = __popcll(bf), nnear = __popcll(bn);
+    __syncthreads();   // previous tile's far records fully consumed
+    if (nn + nnear > kNearCap) {   // wave-uniform: evaluate the pending near sources before the list overflows
+      flush_near();
+      __syncthreads();
+    }
+    if (is_far) {
+      const int q = __popcll(bf & below);
+      farB[q * 2] = V{p[0], p[1]};
+      farB[q * 2 + 1] = V{p[2], ss};
+      farF[q] = f;
+    } else if (is_near) {
+      const int q = nn + __popcll(bn & below);
+      nearA[q * 2] = V{x[0], x[1]};
+      nearA[q * 2 + 1] = V{x[2], f};
+    }
+    nn += nnear;
+    // pad the far list to a multiple of UNR with null sources (zero density at ~1e3 cluster radii): they contribute
+    // exactly 0 and remove the low-ILP remainder loop
+    if (lane < UNR - 1) {
+      const int q = nfar + lane;
+      if (q < ((nfar + UNR - 1) & ~(UNR - 1))) { farB[q * 2] = V{far_off, 0.0}; farB[q * 2 + 1] = V{0.0, far_off * far_off}; farF[q] = 0.0; }
+    }
+    if (it + 1 < ntile) load_source(it + 1);
+    __syncthreads();
+
+    // ---- far sources: 4-instruction distance, no mask -------------------------------------------------------
+    for (int s = 0; s < nfar; s += UNR) {
+#pragma unroll
+      for (int u = 0; u < UNR; u++) {
+        const V b0 = farB[(s + u) * 2], b1 = farB[(s + u) * 2 + 1];
+        const R fs = farF[s + u];
+#pragma unroll
+        for (int j = 0; j < T; j++) {
+          const R r2 = fma_(m2x[j][0], b0[0], fma_(m2x[j][1], b0[1], fma_(m2x[j][2], b1[0], tt[j] + b1[1])));
+          acc[j] = fma_(fs, rsqrt_masked<MODE, false>(r2, K.rsq), acc[j]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  flush_near();
+
+#pragma unroll
+  for (int j = 0; j < T; j++) {
+    const int64_t t = tbase + j * kWaveBlock + lane;
+    if (t < a.Nt) {
+      if (gridDim.y == 1) a.v_trg[t] += acc[j] * a.scale;
+      else a.partial[(int64_t)blockIdx.y * a.Nt + t] = acc[j];
+    }
+  }
+}
+
+// ---- Morton ordering of the targets (host side drives these through rocPRIM's radix sort, capi.hip) ---------
+// per-block bounding boxes -> bbox[block][6]
+template <class R> __global__ void __launch_bounds__(kBlock) bbox_partial_kernel(const R* x, int64_t n, double* part) {
+  __shared__ double red[4 * 6];
+  double lo[3] = {1.7976931348623157e308, 1.7976931348623157e308, 1.7976931348623157e308}, hi[3] = {-lo[0], -lo[0], -lo[0]};
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const double v = (double)x[i * 3 + k];
+      lo[k] = (v < lo[k]) ? v : lo[k];
+      hi[k] = (v > hi[k]) ? v : hi[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) { lo[k] = wave_min(lo[k]); hi[k] = wave_max(hi[k]); }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) { red[wave * 6 + k] = lo[k]; red[wave * 6 + 3 + k] = hi[k]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int k = threadIdx.x;
+    double v = red[k];
+    for (int w = 1; w < 4; w++) v = (k < 3) ? ((red[w * 6 + k] < v) ? red[w * 6 + k] : v) : ((red[w * 6 + k] > v) ? red[w * 6 + k] : v);
+    part[blockIdx.x * 6 + k] = v;
+  }
+}
+
+__device__ __forceinline__ uint64_t spread21(uint64_t v) {   // 21 bits -> every third bit
+  v &= 0x1fffffull;
+  v = (v | (v << 32)) & 0x1f00000000ffffull;
+  v = (v | (v << 16)) & 0x1f0000ff0000ffull;
+  v = (v | (v << 8)) & 0x100f00f00f00f00full;
+  v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+  v = (v | (v << 2)) & 0x1249249249249249ull;
+  return v;
+}
+
+// final bbox from the per-block ones (read by every thread: nblk is small), then 63-bit Morton keys + identity index
+template <class R> __global__ void __launch_bounds__(kBlock) morton_keys_kernel(const R* x, int64_t n, const double* part, int nblk, uint64_t* keys, uint32_t* idx) {
+  __shared__ double box[6];
+  if (threadIdx.x < 6) {
+    const int k = threadIdx.x;
+    double v = part[k];
+    for (int b = 1; b < nblk; b++) v = (k < 3) ? ((part[b * 6 + k] < v) ? part[b * 6 + k] : v) : ((part[b * 6 + k] > v) ? part[b * 6 + k] : v);
+    box[k] = v;
+  }
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  uint64_t key = 0;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const double w = box[3 + k] - box[k];
+    const double q = (w > 0) ? ((double)x[i * 3 + k] - box[k]) / w * 2097151.0 : 0.0;
+    const uint64_t qi = (q > 0) ? (uint64_t)((q < 2097151.0) ? q : 2097151.0) : 0ull;   // NaN -> 0
+    key |= spread21(qi) << k;
+  }
+  keys[i] = key;
+  idx[i] = (uint32_t)i;
+}
+
+template <class R> __global__ void __launch_bounds__(kBlock) gather_points_kernel(const R* x, const uint32_t* perm, int64_t n, R* out) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int64_t s = perm[i];
+#pragma unroll
+  for (int k = 0; k < 3; k++) out[i * 3 + k] = x[s * 3 + k];
+}
+
+// v_trg[perm[i]*K1 + k] += sorted[i*K1 + k]   (sorted already carries the scale factor)
+template <class R> __global__ void __launch_bounds__(kBlock) scatter_add_kernel(const R* sorted, const uint32_t* perm, int64_t n, int k1, R* v_trg) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int64_t t = perm[i];
+  for (int k = 0; k < k1; k++) v_trg[t * k1 + k] += sorted[i * k1 + k];
+}
+
+}  // namespace sctl_amd

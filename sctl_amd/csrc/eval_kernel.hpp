@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(kBlock) eval_kernel(const EvalArgs<R> a) {
 
   const int tid = threadIdx.x;
   const int64_t tbase = (int64_t)blockIdx.x * (kBlock * T);
-  const RsqConst<R> K;
+  const typename Ker::template Consts<R> K;
 
   R xt[T][3], acc[T][K1];
 #pragma unroll
@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(kBlock) matrix_kernel(int64_t Nt, int64_t Ns, 
   constexpr int K0 = Ker::K0, K1 = Ker::K1, ND = Ker::ND, NREC = Ker::NREC;
   const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (t >= Nt) return;
-  const RsqConst<R> K;
+  const typename Ker::template Consts<R> K;
   for (int64_t s = blockIdx.y; s < Ns; s += gridDim.y) {   // gridDim.y is capped at 65535
   R x[3], n[3] = {0, 0, 0}, d[3];
 #pragma unroll

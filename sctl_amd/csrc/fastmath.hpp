@@ -1,0 +1,111 @@
+// fp64 sincos and exp for the Helmholtz kernel, written as straight-line fp64 FMA code (no tables, no divergent
+// branches in the common range) so that a wave64 spends ~26 + ~18 fp64 issue slots instead of the ~80 of the generic
+// device libm calls.  Host-and-device functions: tests/cpp/fastmath_check.cpp verifies them on the CPU against libm
+// (max error ~1 ulp of the result's magnitude scale), the GPU parity tests cover the device build.
+//
+// The reference offers the CPU counterparts approx_sincos / approx_exp (include/sctl/vec.hpp:380-384,
+// include/sctl/intrin-wrapper.hpp:640-778); nothing of their implementation is used here.
+//   sincos: Cody-Waite reduction by pi/2 in three pieces (exact products for |n| < 2^20), degree-13/14 minimax
+//           polynomials on [-pi/4, pi/4] (the classic fdlibm kernel coefficients), quadrant fix-up by sign/swap.
+//           |x| > 1.6e6 takes the libm path (wave-uniform branch; never taken for k r of physical interest).
+//   exp:    n = rint(x log2 e), r = x - n ln2 (two pieces), degree-13 Taylor/Horner on |r| <= ln2/2, scale by 2^n.
+#pragma once
+#include <cmath>
+#ifdef __HIPCC__
+#include <hip/hip_runtime.h>
+#define SCTL_AMD_HD __host__ __device__ __forceinline__
+#else
+#define SCTL_AMD_HD inline
+#endif
+
+namespace sctl_amd {
+namespace fastmath {
+
+SCTL_AMD_HD double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// All non-inline constants of sincos/exp.  On the device the kernel constructs ONE Coeffs at entry and pins every
+// member in a scalar register pair (pin()), so each polynomial step is a single v_fma_f64 with an SGPR operand; left to
+// itself hipcc re-materialises the 25 literals with v_mov_b64 per use (24 extra VALU instructions per pair).
+struct Coeffs {
+  double S[6], C[6], two_over_pi, pio2[3], log2e, ln2hi, ln2lo, E[12];
+  SCTL_AMD_HD Coeffs() {
+    S[0] = -1.66666666666666324348e-01; S[1] = 8.33333333332248946124e-03; S[2] = -1.98412698298579493134e-04;
+    S[3] = 2.75573137070700676789e-06; S[4] = -2.50507602534068634195e-08; S[5] = 1.58969099521155010221e-10;
+    C[0] = 4.16666666666666019037e-02; C[1] = -1.38888888888741095749e-03; C[2] = 2.48015872894767294178e-05;
+    C[3] = -2.75573143513906633035e-07; C[4] = 2.08757232129817482790e-09; C[5] = -1.13596475577881948265e-11;
+    two_over_pi = 6.36619772367581382433e-01;
+    pio2[0] = -1.57079632673412561417e+00;   // -(pi/2), first 33 bits
+    pio2[1] = -6.07710050630396597660e-11;   // next 33 bits
+    pio2[2] = -2.02226624879595063154e-21;   // tail
+    log2e = 1.44269504088896338700e+00;
+    ln2hi = -6.93147180369123816490e-01;
+    ln2lo = -1.90821492927058770002e-10;
+    E[0] = 1.6666666666666666e-01;  E[1] = 4.1666666666666664e-02;  E[2] = 8.3333333333333332e-03;  E[3] = 1.3888888888888889e-03;   // 1/3! ..
+    E[4] = 1.9841269841269841e-04;  E[5] = 2.4801587301587302e-05;  E[6] = 2.7557319223985888e-06;  E[7] = 2.7557319223985893e-07;
+    E[8] = 2.5052108385441720e-08;  E[9] = 2.0876756987868100e-09;  E[10] = 1.6059043836821613e-10; E[11] = 1.1470745597729725e-11; // .. 1/14!
+  }
+#ifdef __HIPCC__
+  __device__ __forceinline__ void pin() {
+    for (int i = 0; i < 6; i++) { asm volatile("" : "+s"(S[i])); asm volatile("" : "+s"(C[i])); }
+    for (int i = 0; i < 3; i++) asm volatile("" : "+s"(pio2[i]));
+    for (int i = 0; i < 12; i++) asm volatile("" : "+s"(E[i]));
+    asm volatile("" : "+s"(two_over_pi)); asm volatile("" : "+s"(log2e)); asm volatile("" : "+s"(ln2hi)); asm volatile("" : "+s"(ln2lo));
+  }
+#endif
+};
+
+// sin(y), cos(y) for |y| <= pi/4 (+ a little): kernel polynomials
+SCTL_AMD_HD void sincos_kernel(double y, double& s, double& c, const Coeffs& K) {
+  const double z = y * y;
+  double ps = K.S[5];
+  ps = fma_(ps, z, K.S[4]);
+  ps = fma_(ps, z, K.S[3]);
+  ps = fma_(ps, z, K.S[2]);
+  ps = fma_(ps, z, K.S[1]);
+  ps = fma_(ps, z, K.S[0]);
+  s = fma_(y * z, ps, y);
+  double pc = K.C[5];
+  pc = fma_(pc, z, K.C[4]);
+  pc = fma_(pc, z, K.C[3]);
+  pc = fma_(pc, z, K.C[2]);
+  pc = fma_(pc, z, K.C[1]);
+  pc = fma_(pc, z, K.C[0]);
+  c = fma_(z * z, pc, fma_(z, -0.5, 1.0));
+}
+
+constexpr double kSincosMaxArg = 1.6e6;   // n < 2^20: the three-piece reduction below stays accurate
+
+// precondition: |x| <= kSincosMaxArg (the caller routes larger arguments to libm)
+SCTL_AMD_HD void sincos_reduced(double x, double& s, double& c, const Coeffs& K) {
+  const double n = __builtin_rint(x * K.two_over_pi);
+  double y = fma_(n, K.pio2[0], x);
+  y = fma_(n, K.pio2[1], y);
+  y = fma_(n, K.pio2[2], y);
+  double sk, ck;
+  sincos_kernel(y, sk, ck, K);
+  const int q = (int)n;
+  const bool swap = (q & 1) != 0;
+  const double s0 = swap ? ck : sk, c0 = swap ? sk : ck;
+  s = (q & 2) ? -s0 : s0;
+  c = ((q + 1) & 2) ? -c0 : c0;
+}
+
+SCTL_AMD_HD double exp_fast(double x, const Coeffs& K) {
+  // clamp so that n fits an int and ldexp saturates to 0 / inf correctly
+  const double xc = __builtin_fmin(__builtin_fmax(x, -800.0), 800.0);   // v_max_f64 / v_min_f64; a NaN is restored below
+  const double n = __builtin_rint(xc * K.log2e);
+  double r = fma_(n, K.ln2hi, xc);
+  r = fma_(n, K.ln2lo, r);
+  double p = K.E[10];                       // 1/13!
+#if defined(__clang__)
+#pragma unroll
+#endif
+  for (int i = 9; i >= 0; i--) p = fma_(p, r, K.E[i]);
+  p = fma_(p, r, 0.5);
+  p = fma_(p * r, r, r) + 1.0;              // 1 + r + r^2 p
+  const double e = __builtin_ldexp(p, (int)n);
+  return (x != x) ? x : e;                  // NaN in -> NaN out
+}
+
+}  // namespace fastmath
+}  // namespace sctl_amd

@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "fastmath.hpp"
+
 namespace sctl_amd {
 
 constexpr double kPi = 3.141592653589793238462643383279502884;
@@ -76,6 +78,14 @@ template <int MODE, bool MASKED> __device__ __forceinline__ float rsqrt_masked(f
   return y;
 }
 
+// Per-kernel constants, constructed once at kernel entry and passed to every pair() call.
+template <class R> struct DefaultConsts { RsqConst<R> rsq; };
+template <class R> struct HelmholtzConsts {
+  RsqConst<R> rsq;
+  fastmath::Coeffs fm;
+  __device__ __forceinline__ HelmholtzConsts() { fm.pin(); }
+};
+
 template <class R> __device__ __forceinline__ R fma_(R a, R b, R c);
 template <> __device__ __forceinline__ double fma_<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
 template <> __device__ __forceinline__ float fma_<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
@@ -87,12 +97,13 @@ template <class R> __device__ __forceinline__ R dot3(const R (&d)[3], const R* v
 struct Laplace3D_FxU {
   static constexpr int ID = 0, K0 = 1, K1 = 1, ND = 0, NREC = 4, FLOPS = 6;
   static constexpr const char* NAME = "Laplace3D-FxU";
+  template <class R> using Consts = DefaultConsts<R>;
   static constexpr double scale() { return 1 / (4 * kPi); }
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0];
   }
-  template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const RsqConst<R>& K) {
-    const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K);
+  template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const Consts<R>& K) {
+    const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K.rsq);
     acc[0] = fma_(rec[3], rinv, acc[0]);
   }
 };
@@ -101,12 +112,13 @@ struct Laplace3D_FxU {
 struct Laplace3D_DxU {
   static constexpr int ID = 1, K0 = 1, K1 = 1, ND = 3, NREC = 6, FLOPS = 14;
   static constexpr const char* NAME = "Laplace3D-DxU";
+  template <class R> using Consts = DefaultConsts<R>;
   static constexpr double scale() { return 1 / (4 * kPi); }
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R* n, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = n[0] * f[0]; rec[4] = n[1] * f[0]; rec[5] = n[2] * f[0];
   }
-  template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const RsqConst<R>& K) {
-    const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K);
+  template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const Consts<R>& K) {
+    const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K.rsq);
     const R rinv3 = rinv * rinv * rinv;
     acc[0] = fma_(dot3(d, rec + 3), rinv3, acc[0]);
   }
@@ -116,12 +128,13 @@ struct Laplace3D_DxU {
 struct Laplace3D_FxdU {
   static constexpr int ID = 2, K0 = 1, K1 = 3, ND = 0, NREC = 4, FLOPS = 11;
   static constexpr const char* NAME = "Laplace3D-FxdU";
+  template <class R> using Consts = DefaultConsts<R>;
   static constexpr double scale() { return -1 / (4 * kPi); }
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0];
   }
-  template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const RsqConst<R>& K) {
-    const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K);
+  template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const Consts<R>& K) {
+    const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K.rsq);
     const R t = rinv * rinv * rinv * rec[3];
     for (int j = 0; j < 3; j++) acc[j] = fma_(t, d[j], acc[j]);
   }
@@ -131,12 +144,13 @@ struct Laplace3D_FxdU {
 struct Stokes3D_FxU {
   static constexpr int ID = 3, K0 = 3, K1 = 3, ND = 0, NREC = 6, FLOPS = 23;
   static constexpr const char* NAME = "Stokes3D-FxU";
+  template <class R> using Consts = DefaultConsts<R>;
   static constexpr double scale() { return 1 / (8 * kPi); }
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0]; rec[4] = f[1]; rec[5] = f[2];
   }
-  template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const RsqConst<R>& K) {
-    const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K);
+  template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const Consts<R>& K) {
+    const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K.rsq);
     const R t = dot3(d, rec + 3) * (rinv * rinv * rinv);
     for (int j = 0; j < 3; j++) acc[j] = fma_(t, d[j], fma_(rinv, rec[3 + j], acc[j]));
   }
@@ -146,13 +160,14 @@ struct Stokes3D_FxU {
 struct Stokes3D_DxU {
   static constexpr int ID = 4, K0 = 3, K1 = 3, ND = 3, NREC = 10, FLOPS = 26;
   static constexpr const char* NAME = "Stokes3D-DxU";
+  template <class R> using Consts = DefaultConsts<R>;
   static constexpr double scale() { return 3 / (4 * kPi); }
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R* n, const R* f) {
     for (int k = 0; k < 3; k++) { rec[k] = x[k]; rec[3 + k] = n[k]; rec[6 + k] = f[k]; }
     rec[9] = 0;
   }
-  template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const RsqConst<R>& K) {
-    const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K);
+  template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const Consts<R>& K) {
+    const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K.rsq);
     const R rinv2 = rinv * rinv;
     const R t = dot3(d, rec + 3) * dot3(d, rec + 6) * (rinv2 * rinv2 * rinv);
     for (int j = 0; j < 3; j++) acc[j] = fma_(t, d[j], acc[j]);
@@ -163,12 +178,13 @@ struct Stokes3D_DxU {
 struct Stokes3D_FxT {
   static constexpr int ID = 5, K0 = 3, K1 = 9, ND = 0, NREC = 6, FLOPS = 39;
   static constexpr const char* NAME = "Stokes3D-FxT";
+  template <class R> using Consts = DefaultConsts<R>;
   static constexpr double scale() { return -3 / (4 * kPi); }
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0]; rec[4] = f[1]; rec[5] = f[2];
   }
-  template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const RsqConst<R>& K) {
-    const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K);
+  template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const Consts<R>& K) {
+    const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K.rsq);
     const R rinv2 = rinv * rinv;
     const R t = dot3(d, rec + 3) * (rinv2 * rinv2 * rinv);
     for (int j = 0; j < 3; j++) {
@@ -182,12 +198,13 @@ struct Stokes3D_FxT {
 struct Stokes3D_FSxU {
   static constexpr int ID = 6, K0 = 4, K1 = 3, ND = 0, NREC = 8, FLOPS = 26;
   static constexpr const char* NAME = "Stokes3D-FSxU";
+  template <class R> using Consts = DefaultConsts<R>;
   static constexpr double scale() { return 1 / (8 * kPi); }
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0]; rec[4] = f[1]; rec[5] = f[2]; rec[6] = f[3]; rec[7] = 0;
   }
-  template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const RsqConst<R>& K) {
-    const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K);
+  template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const Consts<R>& K) {
+    const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K.rsq);
     const R t = (dot3(d, rec + 3) + rec[6]) * (rinv * rinv * rinv);
     for (int j = 0; j < 3; j++) acc[j] = fma_(t, d[j], fma_(rinv, rec[3 + j], acc[j]));
   }
@@ -197,12 +214,13 @@ struct Stokes3D_FSxU {
 struct Stokes3D_FxUP {
   static constexpr int ID = 7, K0 = 3, K1 = 4, ND = 0, NREC = 6, FLOPS = 26;
   static constexpr const char* NAME = "Stokes3D-FxUP";
+  template <class R> using Consts = DefaultConsts<R>;
   static constexpr double scale() { return 1 / (8 * kPi); }
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0]; rec[4] = f[1]; rec[5] = f[2];
   }
-  template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const RsqConst<R>& K) {
-    const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K);
+  template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const Consts<R>& K) {
+    const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K.rsq);
     const R t = dot3(d, rec + 3) * (rinv * rinv * rinv);
     for (int j = 0; j < 3; j++) acc[j] = fma_(t, d[j], fma_(rinv, rec[3 + j], acc[j]));
     acc[3] += t;
@@ -215,13 +233,14 @@ struct Stokes3D_FxUP {
 struct Laplace3D_FDxUdU {
   static constexpr int ID = 8, K0 = 2, K1 = 4, ND = 3, NREC = 8, FLOPS = 28;
   static constexpr const char* NAME = "Laplace3D-FDxUdU";
+  template <class R> using Consts = DefaultConsts<R>;
   static constexpr double scale() { return 1 / (4 * kPi); }
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R* n, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2];
     rec[3] = n[0] * f[1]; rec[4] = n[1] * f[1]; rec[5] = n[2] * f[1]; rec[6] = f[0]; rec[7] = 0;
   }
-  template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const RsqConst<R>& K) {
-    const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K);
+  template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const Consts<R>& K) {
+    const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K.rsq);
     const R rinv2 = rinv * rinv;
     const R rinv3 = rinv2 * rinv;
     const R a = dot3(d, rec + 3) * rinv3;               // mu (r.n) / r^3
@@ -236,25 +255,34 @@ struct Laplace3D_FDxUdU {
 struct Helmholtz3D_FxU {
   static constexpr int ID = 9, K0 = 2, K1 = 2, ND = 0, NREC = 6, FLOPS = 16;
   static constexpr const char* NAME = "Helmholtz3D-FxU";
+  template <class R> using Consts = HelmholtzConsts<R>;
   static constexpr double scale() { return 1 / (4 * kPi); }
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0]; rec[4] = f[1]; rec[5] = 0;
   }
-  template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx& ctx, const RsqConst<R>& K) {
+  template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx& ctx, const Consts<R>& K) {
     const R r2 = len2(d);
-    const R rinv = rsqrt_masked<MODE, MASKED>(r2, K);
+    const R rinv = rsqrt_masked<MODE, MASKED>(r2, K.rsq);
     const R r = r2 * rinv;
     R sn, cs;
-    sincos_(R(ctx.v[0]) * r, sn, cs);
-    const R amp = exp_(-R(ctx.v[1]) * r) * rinv;
+    sincos_(R(ctx.v[0]) * r, sn, cs, K.fm);
+    const R amp = exp_(-R(ctx.v[1]) * r, K.fm) * rinv;
     const R gr = amp * cs, gi = amp * sn;
     acc[0] = fma_(gr, rec[3], fma_(-gi, rec[4], acc[0]));
     acc[1] = fma_(gi, rec[3], fma_(gr, rec[4], acc[1]));
   }
-  static __device__ __forceinline__ void sincos_(double x, double& s, double& c) { ::sincos(x, &s, &c); }
-  static __device__ __forceinline__ void sincos_(float x, float& s, float& c) { ::sincosf(x, &s, &c); }
-  static __device__ __forceinline__ double exp_(double x) { return ::exp(x); }
-  static __device__ __forceinline__ float exp_(float x) { return ::expf(x); }
+  // fp64: straight-line Cody-Waite + polynomial code (fastmath.hpp); arguments beyond 1.6e6 take the libm path
+  static __device__ __forceinline__ void sincos_(double x, double& s, double& c, const fastmath::Coeffs& fm) {
+#ifdef SCTL_AMD_EXPERIMENT_NO_LIBM_FALLBACK   // experiment switch only (tools/): wrong beyond |x| = 1.6e6
+    fastmath::sincos_reduced(x, s, c, fm);
+#else
+    if (__builtin_expect(__builtin_fabs(x) > fastmath::kSincosMaxArg, 0)) ::sincos(x, &s, &c);
+    else fastmath::sincos_reduced(x, s, c, fm);
+#endif
+  }
+  static __device__ __forceinline__ void sincos_(float x, float& s, float& c, const fastmath::Coeffs&) { ::sincosf(x, &s, &c); }
+  static __device__ __forceinline__ double exp_(double x, const fastmath::Coeffs& fm) { return fastmath::exp_fast(x, fm); }
+  static __device__ __forceinline__ float exp_(float x, const fastmath::Coeffs&) { return ::expf(x); }
 };
 
 }  // namespace sctl_amd

@@ -1,0 +1,33 @@
+// CPU check of sctl_amd/csrc/fastmath.hpp (the fp64 sincos / exp used by the Helmholtz device kernel) against libm in
+// long double.  Prints the maximum errors; tests/test_fastmath.py asserts the bounds.  Built with g++ (no HIP needed).
+#include "../../sctl_amd/csrc/fastmath.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+int main() {
+  using namespace sctl_amd::fastmath;
+  const Coeffs K;
+  srand48(1);
+  double es = 0, ec = 0, ee = 0;
+  for (int i = 0; i < 4000000; i++) {
+    const double scale = (i % 4 == 0) ? 1.0 : (i % 4 == 1) ? 30.0 : (i % 4 == 2) ? 3000.0 : 1.5e6;
+    const double x = (drand48() * 2 - 1) * scale;
+    double s, c;
+    sincos_reduced(x, s, c, K);
+    const long double sl = sinl((long double)x), cl = cosl((long double)x);
+    es = fmax(es, fabs((double)(s - sl)));
+    ec = fmax(ec, fabs((double)(c - cl)));
+    const double t = (drand48() * 2 - 1) * ((i % 2) ? 5.0 : 700.0);
+    const long double el = expl((long double)t);
+    ee = fmax(ee, fabs((double)((exp_fast(t, K) - el) / el)));
+  }
+  // specials
+  const double z = exp_fast(-1e9, K), big = exp_fast(1e9, K), one = exp_fast(0.0, K), nn = exp_fast(NAN, K);
+  double s0, c0;
+  sincos_reduced(0.0, s0, c0, K);
+  printf("max_abs_err_sin %.3e\nmax_abs_err_cos %.3e\nmax_rel_err_exp %.3e\n", es, ec, ee);
+  printf("specials %d\n", (z == 0.0) && std::isinf(big) && (one == 1.0) && (nn != nn) && (s0 == 0.0) && (c0 == 1.0));
+  return 0;
+}

@@ -75,13 +75,18 @@ def test_launch_planner():
             for N in (1, 300, 1 << 14, 1 << 18, 1 << 20, 1 << 23):
                 p = sctl_amd.plan(name, real, N, N)
                 assert p["trg_per_lane"] in (1, 2, 4) and p["src_splits"] >= 1
-                assert p["workgroups"] >= min(1024, ((N + 255) // 256) * ((N + 255) // 256))
+                if p["path"] == "exact":
+                    assert p["workgroups"] >= min(1024, ((N + 255) // 256) * ((N + 255) // 256))
                 k1 = sctl_amd.kernel_info(name)["k1"]
                 assert p["workspace_bytes"] == (0 if p["src_splits"] == 1 else p["src_splits"] * N * k1 * (8 if real == 0 else 4))
-    big = sctl_amd.plan("Laplace3D-FxU", 0, 1 << 20, 1 << 20)
-    assert big["src_splits"] == 1 and big["workspace_bytes"] == 0 and big["trg_per_lane"] == 2
+    big = sctl_amd.plan("Stokes3D-FxU", 0, 1 << 20, 1 << 20)
+    assert big["src_splits"] == 1 and big["workspace_bytes"] == 0 and big["trg_per_lane"] == 2 and big["path"] == "exact"
     small = sctl_amd.plan("Laplace3D-FxU", 0, 1 << 14, 1 << 14)
-    assert small["src_splits"] > 1
+    assert small["src_splits"] > 1 and small["path"] == "exact"
+    if os.environ.get("SCTL_AMD_CENTERED") != "0":      # the headline problem takes the tile-centred Laplace path: one wave per workgroup
+        head = sctl_amd.plan("Laplace3D-FxU", 0, 1 << 20, 1 << 20)
+        assert head["path"] == "tile-centred" and head["src_splits"] == 16 and head["workgroups"] == 8192 * 16
+        assert sctl_amd.plan("Laplace3D-FxU", 1, 1 << 20, 1 << 20)["path"] == "exact"      # fp32 stays on the exact kernel
 
 
 def test_product_tree_never_touches_the_oracle():

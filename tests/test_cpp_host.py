@@ -8,17 +8,14 @@ import numpy as np
 import pytest
 
 import sctl_amd
-from conftest import ROOT, rel_l2
+from conftest import ROOT, golden_array, load_manifest, rel_l2
 from sctl_amd.rand48 import Rand48
 
-SRC = os.path.join(ROOT, "tests", "cpp", "fmm_driver.cpp")
-
-
-def _build(tmp_path):
-    exe = str(tmp_path / "fmm_driver")
+def _build(tmp_path, name="fmm_driver"):
+    exe = str(tmp_path / name)
     libdir = os.path.join(ROOT, "sctl_amd")
-    cmd = ["g++", "-std=c++11", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), SRC, "-L" + libdir, "-lsctl_amd",
-           "-Wl,-rpath," + libdir, "-o", exe]
+    cmd = ["g++", "-std=c++11", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", name + ".cpp"),
+           "-L" + libdir, "-lsctl_amd", "-Wl,-rpath," + libdir, "-o", exe]
     subprocess.run(cmd, check=True)
     return exe
 
@@ -69,3 +66,52 @@ def test_particle_fmm_driver_matches_oracle(tmp_path, O):
     # SCTL-convention flops = pairs * FLOPS() (generic-kernel.txx:188)
     assert "pair interactions: %d " % (N * N * 8 + 33 * 20) in p.stdout
     assert "flops: %d" % (N * N * (4 * 26 + 3 * 23 + 16) + 33 * 20 * 26) in p.stdout
+
+
+FAR = [c for c in load_manifest()["cases"] if c["kind"] == "far_field"]
+
+
+def _far_inputs(c, k0):
+    """oracle/gen_golden.py:far_field_inputs — targets, target normals, nodes, node normals, weights, density."""
+    g = Rand48(c["seed"])
+    xt = g.drand48(c["Nt"] * 3) - 0.5
+    xnt = g.drand48(c["Nt"] * 3) - 0.5
+    xs = g.drand48(c["Ns"] * 3) - 0.5
+    xn = g.drand48(c["Ns"] * 3) - 0.5
+    w = g.drand48(c["Ns"]) * 0.01
+    f = g.drand48(c["Ns"] * k0) - 0.5
+    return xt, xnt, xs, xn, w, f
+
+
+@pytest.mark.parametrize("case", FAR, ids=lambda c: "%s-%s" % (c["kernel"], c["key"]))
+def test_far_field_restatement_matches_reference(O, oracle_mod, case):
+    """CPU: the oracle's restatement of BoundaryIntegralOp::ComputeFarField vs the reference's ComputePotential output."""
+    xt, xnt, xs, xn, w, f = _far_inputs(case, O.info(case["kernel"])["k0"])
+    u = oracle_mod.far_field_restatement(O, case["kernel"], None if case["self_targets"] else xt, xnt, xs, xn, w, f,
+                                         bool(case["trg_normal_dot_prod"]))
+    ref = golden_array(case["kernel"], case["key"])
+    assert u.shape == ref.shape and rel_l2(u, ref) < 1e-10      # the reference ran at tol 1e-10 -> 11 digits
+
+
+def test_boundary_integral_header_compiles_and_fails_loudly_without_gpu(tmp_path):
+    exe = _build(tmp_path, "bie_driver")
+    if sctl_amd.device_count() > 0:
+        pytest.skip("a GPU is present")
+    p = subprocess.run([exe, "Laplace3D-FxU", "1", "10", "20", "4", "2", "0", "0", str(tmp_path / "o.bin")], capture_output=True, text=True)
+    assert p.returncode != 0 and "no HIP device" in p.stderr
+
+
+@pytest.mark.gpu
+def test_boundary_integral_far_field_matches_reference(tmp_path):
+    """GPU: include/sctl_amd/boundary_integral.hpp (BoundaryIntegralOp far field -> ParticleFMM -> HIP kernels) against
+    the REAL reference's BoundaryIntegralOp::ComputePotential on the same element list and inputs."""
+    exe = _build(tmp_path, "bie_driver")
+    for c in FAR:
+        out = str(tmp_path / (c["key"] + ".bin"))
+        args = [exe, c["kernel"], str(c["seed"]), str(c["Nt"]), str(c["Ns"]), str(c["nodes_per_elem"]), str(c["upsample"]),
+                str(c["trg_normal_dot_prod"]), str(c["self_targets"]), out]
+        p = subprocess.run(args, capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0, p.stderr
+        u = _read_vector(out)
+        ref = golden_array(c["kernel"], c["key"])
+        assert u.shape == ref.shape and rel_l2(u, ref) < 1e-10, (c["key"], rel_l2(u, ref))

@@ -1,0 +1,16 @@
+"""CPU check of the fp64 sincos / exp the Helmholtz device kernel uses (sctl_amd/csrc/fastmath.hpp is host+device code)."""
+import os
+import re
+import subprocess
+
+from conftest import ROOT
+
+
+def test_fastmath_against_libm(tmp_path):
+    exe = str(tmp_path / "fastmath_check")
+    subprocess.run(["g++", "-O2", "-std=c++14", "-ffp-contract=off", os.path.join(ROOT, "tests", "cpp", "fastmath_check.cpp"), "-o", exe], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout
+    v = {k: float(x) for k, x in re.findall(r"(\w+) ([0-9.e+-]+)", out)}
+    assert v["max_abs_err_sin"] < 4e-16 and v["max_abs_err_cos"] < 4e-16      # |x| up to 1.5e6
+    assert v["max_rel_err_exp"] < 4e-16                                        # |x| up to 700
+    assert v["specials"] == 1                                                  # exp(-huge)=0, exp(huge)=inf, exp(0)=1, NaN, sincos(0)

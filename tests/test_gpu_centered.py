@@ -1,0 +1,74 @@
+"""The tile-centred Laplace path (sctl_amd/csrc/centered_kernel.hpp): Morton-sorted targets, far sources through the
+expanded distance, near sources exact.  Checked against the CPU oracle on a target subset and against the exact all-pairs
+kernel (SCTL_AMD_CENTERED=0) on ALL targets, for point distributions that stress the far/near split."""
+import os
+
+import numpy as np
+import pytest
+
+import sctl_amd
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+NT, NS = (1 << 18) + 37, 70001      # ragged: not multiples of the 128-target wave or the 64-source tile
+
+
+def _clouds(kind, rng):
+    if kind == "uniform":
+        return rng.random((NT, 3)), rng.random((NS, 3))
+    if kind == "clustered":          # targets in tight clusters, sources inside and far outside them
+        centres = rng.random((50, 3))
+        xt = centres[rng.integers(0, 50, NT)] + 1e-3 * rng.standard_normal((NT, 3))
+        xs = np.concatenate([centres[rng.integers(0, 50, NS // 2)] + 1e-3 * rng.standard_normal((NS // 2, 3)), 10 * rng.random((NS - NS // 2, 3))])
+        return xt, xs
+    if kind == "surface":            # both on a sphere (a boundary-integral discretisation), sources = a subset of the targets
+        v = rng.standard_normal((NT, 3))
+        xt = v / np.linalg.norm(v, axis=1, keepdims=True)
+        return xt, xt[rng.choice(NT, NS, replace=False)].copy()
+    if kind == "identical_targets":  # zero cluster radius: every source is "far" unless it coincides with the target
+        xt = np.tile(np.array([[0.3, 0.4, 0.5]]), (NT, 1))
+        xs = rng.random((NS, 3))
+        xs[:10] = xt[0]
+        return xt, xs
+    if kind == "offset":             # large common offset: centring must not lose the small separations
+        return 1.0e4 + 1e-2 * rng.random((NT, 3)), 1.0e4 + 1e-2 * rng.random((NS, 3))
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "clustered", "surface", "identical_targets", "offset"])
+def test_centred_path_matches_oracle_and_exact_kernel(O, kind):
+    import torch
+    rng = np.random.default_rng(123)
+    xt, xs = _clouds(kind, rng)
+    xt, xs = np.ascontiguousarray(xt.ravel()), np.ascontiguousarray(xs.ravel())
+    f = rng.random(NS) - 0.5
+    assert sctl_amd.plan("Laplace3D-FxU", 0, NT, NS)["path"] == "tile-centred"
+    d = [torch.from_numpy(a).cuda() for a in (xt, xs, f)]
+    u = sctl_amd.eval_device("Laplace3D-FxU", d[0], d[1], None, d[2]).cpu().numpy()
+    assert np.all(np.isfinite(u))
+    os.environ["SCTL_AMD_CENTERED"] = "0"
+    try:
+        assert sctl_amd.plan("Laplace3D-FxU", 0, NT, NS)["path"] == "exact"
+        u_exact = sctl_amd.eval_device("Laplace3D-FxU", d[0], d[1], None, d[2]).cpu().numpy()
+    finally:
+        del os.environ["SCTL_AMD_CENTERED"]
+    assert rel_l2(u, u_exact) <= 2e-14, rel_l2(u, u_exact)
+    sel = rng.choice(NT, 300, replace=False)
+    ref = O.eval("Laplace3D-FxU", xt.reshape(NT, 3)[sel].ravel().copy(), xs, None, f)
+    assert rel_l2(u[sel], ref) <= 1e-12, rel_l2(u[sel], ref)
+
+
+def test_centred_path_accumulates_and_honours_digits(O):
+    import torch
+    rng = np.random.default_rng(5)
+    xt, xs, f = rng.random(NT * 3), rng.random(NS * 3), rng.random(NS) - 0.5
+    d = [torch.from_numpy(a).cuda() for a in (xt, xs, f)]
+    u = sctl_amd.eval_device("Laplace3D-FxU", d[0], d[1], None, d[2])
+    u2 = sctl_amd.eval_device("Laplace3D-FxU", d[0], d[1], None, d[2], v_trg=u.clone())          # accumulate (generic-kernel.txx:184)
+    assert rel_l2(u2.cpu().numpy(), 2 * u.cpu().numpy()) < 1e-15
+    sel = rng.choice(NT, 200, replace=False)
+    ref = O.eval("Laplace3D-FxU", xt.reshape(NT, 3)[sel].ravel().copy(), xs, None, f)
+    for digits, tol in ((3, 1e-2), (7, 1e-6), (12, 1e-11), (-1, 1e-13)):
+        v = sctl_amd.eval_device("Laplace3D-FxU", d[0], d[1], None, d[2], digits=digits).cpu().numpy()
+        assert rel_l2(v[sel], ref) <= tol, (digits, rel_l2(v[sel], ref))
