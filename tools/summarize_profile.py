@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/prof_<tag>/ (written by tools/profile_bench.sh) into the files committed under profiles/:
+  profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (per-kernel calls / average ns)
+  profiles/<tag>_pmc_summary.csv    per-kernel means of the PMC passes (FETCH_SIZE, WRITE_SIZE, SQ_*; one pass each)
+  profiles/hbm_traffic.json         HBM bytes per launch of the dominant kernel, read by bench.py for roofline.traffic
+usage: tools/summarize_profile.py <tag> <workload>"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+tag, workload = sys.argv[1], sys.argv[2]
+P = "gpurun_out/prof_" + tag
+os.makedirs("profiles", exist_ok=True)
+
+
+def short(name):
+    name = name.split("(")[0]
+    for pre in ("void ", "sctl_amd::", "rocprim::ROCPRIM_400200_NS::detail::"):
+        name = name.replace(pre, "")
+    return name[:90]
+
+
+rows = list(csv.DictReader(open(glob.glob(P + "/trace/runc/*_kernel_stats.csv")[0])))
+with open("profiles/%s_kernel_stats.csv" % tag, "w") as fh:
+    fh.write("# rocprofv3 --kernel-trace --stats of: python bench.py --steps 3 --warmup 1 --no-cpu-baseline (workload %s)\n" % workload)
+    fh.write("kernel,calls,total_ns,average_ns,percentage\n")
+    for r in rows:
+        fh.write("%s,%s,%s,%s,%s\n" % (short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]))
+dominant = max(rows, key=lambda r: float(r["TotalDurationNs"]))
+summ = collections.defaultdict(dict)
+meta = {}
+for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(glob.glob("%s/%s/runc/*_counter_collection.csv" % (P, sub))[0])):
+        if "at::native" in r["Kernel_Name"]:
+            continue
+        k = short(r["Kernel_Name"])
+        agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
+        meta[k] = "grid=%s wg=%s lds=%s vgpr=%s sgpr=%s" % (r["Grid_Size"], r["Workgroup_Size"], r["LDS_Block_Size"], r["VGPR_Count"], r["SGPR_Count"])
+    for (k, c), v in agg.items():
+        summ[k][c] = (len(v), sum(v) / len(v))
+with open("profiles/%s_pmc_summary.csv" % tag, "w") as fh:
+    fh.write("# rocprofv3 --pmc passes, FETCH_SIZE / WRITE_SIZE / SQ set each in its OWN run without tracing; mean per launch\n")
+    fh.write("kernel,launch_geometry,counter,launches,mean_per_launch\n")
+    for k, d in summ.items():
+        for c, (n, m) in sorted(d.items()):
+            fh.write("%s,%s,%s,%d,%.6g\n" % (k, meta[k], c, n, m))
+dk = short(dominant["Name"])
+fetch_kb, write_kb = summ[dk]["FETCH_SIZE"][1], summ[dk]["WRITE_SIZE"][1]
+path = "profiles/hbm_traffic.json"
+data = json.load(open(path)) if os.path.exists(path) else {}
+data[workload] = {
+    "kernel": dk, "kernel_average_ms": float(dominant["AverageNs"]) / 1e6,
+    "FETCH_SIZE_KB_raw": fetch_kb, "WRITE_SIZE_KB_raw": write_kb,
+    "hbm_bytes_per_launch": (2 * fetch_kb + write_kb) * 1024,
+    "hbm_bytes_per_launch_uncorrected": (fetch_kb + write_kb) * 1024,
+    "correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE counts 64 B per 128-B request on gfx950 -> read side doubled (an upper bound "
+                  "here: the tile-fill loads are 8/16 B per lane at a 24-B stride, not the calibrated 16 B/lane stream); WRITE_SIZE exact",
+    "source": "profiles/%s_pmc_summary.csv" % tag}
+json.dump(data, open(path, "w"), indent=1)
+print(dk, "avg ms", data[workload]["kernel_average_ms"], "traffic", data[workload]["hbm_bytes_per_launch"])
