@@ -86,7 +86,9 @@ struct Plan {
 // Geometry: enough workgroups for >= 4 per CU; prefer 2 targets per lane (halves LDS reads per pair)
 // once there are enough targets, otherwise split the source range (SURVEY.md §8e sizes: 2^14 .. 2^23).
 Plan make_plan(const KernelEntry& k, int real, int64_t Nt, int64_t Ns) {
-  const int64_t want = (int64_t)cu_count() * 4;
+  // workgroups wanted: 8 per CU (32 waves) — measured +4 % over 4 per CU at Nt = 2^17, Ns = 2^20 and on the Stokeslet at
+  // 2^18 — except for tiny problems, which are launch-bound and lose time to the extra partial sums
+  const int64_t want = (int64_t)cu_count() * ((double)Nt * (double)Ns < 2147483648.0 ? 4 : 8);
   Plan p{};
   int t = (k.k1 * (real == SCTL_AMD_F64 ? 2 : 1) > 8) ? 1 : 2;   // big accumulator sets (Stokes3D-FxT fp64): 1 target per lane
   if ((Nt + kBlock * t - 1) / (kBlock * t) < want) t = 1;
@@ -131,7 +133,7 @@ bool use_centered(const KernelEntry& k, int real, int64_t Nt, int64_t Ns) {
   const char* e = std::getenv("SCTL_AMD_CENTERED");   // read per call so that a test can A/B both paths in one process
   const bool enabled = !(e && e[0] == '0');
   // Nt >= 2^18: below that the 128 targets of a wave span so much of the domain that > 10 % of the sources are "near"
-  // and the exact kernel wins (measured at 2^17: 10.0 ms vs 8.9 ms)
+  // and the exact kernel wins (measured at Nt = 2^17, Ns = 2^20: 67.8 ms vs 65.7 ms; one target per lane does not help: 66.6 ms)
   return enabled && k.id == SCTL_AMD_LAPLACE3D_FXU && real == SCTL_AMD_F64 && Nt >= (1 << 18) && Nt < (int64_t(1) << 32) && Ns >= 65536;
 }
 

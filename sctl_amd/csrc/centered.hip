@@ -26,11 +26,7 @@ struct AsyncBuf {
 };
 
 template <int MODE> void launch_centered(const EvalArgs<double>& a, int T, dim3 grid, hipStream_t st) {
-  static const int variant = [] { const char* e = std::getenv("SCTL_AMD_EXPERIMENT_VARIANT"); return e ? std::atoi(e) : 0; }();   // timing experiments
   if (T == 1) hipLaunchKernelGGL((laplace_fxu_centered_kernel<MODE, 1>), grid, dim3(kWaveBlock), 0, st, a);
-  else if (variant == 1) hipLaunchKernelGGL((laplace_fxu_centered_kernel<MODE, 2, 2, 1>), grid, dim3(kWaveBlock), 0, st, a);
-  else if (variant == 2) hipLaunchKernelGGL((laplace_fxu_centered_kernel<MODE, 2, 4, 6>), grid, dim3(kWaveBlock), 0, st, a);
-  else if (variant == 3) hipLaunchKernelGGL((laplace_fxu_centered_kernel<MODE, 2, 2, 8>), grid, dim3(kWaveBlock), 0, st, a);
   else hipLaunchKernelGGL((laplace_fxu_centered_kernel<MODE, 2>), grid, dim3(kWaveBlock), 0, st, a);
 }
 }  // namespace
@@ -41,7 +37,7 @@ template <int MODE> void launch_centered(const EvalArgs<double>& a, int T, dim3 
 // points), so the source range is split until there are >= 32 "rounds" of workgroups — measured on 2^20 x 2^20:
 // 1 split 517 ms, 4 splits 480 ms, 16 splits 469 ms (exact kernel on the same GPU: 520 ms).
 void centered_plan(int64_t Nt, int64_t Ns, int cus, int* T, int* splits, int64_t* chunk) {
-  *T = 2;
+  *T = 2;   // one target per lane is LDS-bound (3 LDS reads per pair): 498 ms vs 465 ms at 2^20
   const int64_t wg_x = (Nt + kWaveBlock * 2 - 1) / (kWaveBlock * 2);
   const int64_t want = (int64_t)cus * 16 * 32;
   const int64_t ntile = (Ns + kWaveTile - 1) / kWaveTile;

@@ -41,8 +41,8 @@ constexpr int kWaveTile = 64;    // sources per LDS tile
 constexpr int kNearCap = 128;    // capacity of the per-wave list of pending near sources
 
 // a.xt: Morton-sorted targets; a.v_trg / a.partial: indexed like a.xt (the caller scatters back); fp64 only.
-template <int MODE, int T, int UNR = 4, int MINW = 1>
-__global__ void __launch_bounds__(kWaveBlock, MINW) laplace_fxu_centered_kernel(const EvalArgs<double> a) {
+template <int MODE, int T, int UNR = 4>
+__global__ void __launch_bounds__(kWaveBlock) laplace_fxu_centered_kernel(const EvalArgs<double> a) {
   using R = double;
   typedef double V __attribute__((ext_vector_type(2)));
   using Ker = Laplace3D_FxU;
