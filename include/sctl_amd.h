@@ -108,6 +108,22 @@ int sctl_amd_kernel_matrix_device(int kernel, int real, int64_t Nt, int64_t Ns, 
 int sctl_amd_kernel_matrix_host(int kernel, int real, int64_t Nt, int64_t Ns, const void* r_trg, const void* r_src,
                                 const void* n_src, void* M, int digits, const void* ctx, int ctx_bytes, int device);
 
+/* ---- device-resident operator: coordinates stay on the GPUs between evaluations ------------------------------- */
+/* The MI355X-first form of what ParticleFMM keeps between SetSrcCoord/SetTrgCoord and repeated Eval calls
+ * (fmm-wrapper.txx:444-479: the object owns copies of X, Xn, F; boundary_integral.txx:1054,1063: an iterative solver
+ * changes only the density between evaluations).  Coordinates are uploaded once — targets block-partitioned over the
+ * device list with the formula of fmm-wrapper.txx:507, sources replicated — and every sctl_amd_op_eval moves only the
+ * density down and the potential up.  A handle may be used from one thread at a time. */
+typedef struct sctl_amd_op sctl_amd_op;
+int sctl_amd_op_create(int kernel, int real, const int* devices, int n_devices, sctl_amd_op** op);
+/* HOST arrays, copied to the devices before returning; either may be called again at any time (new coordinates). */
+int sctl_amd_op_set_targets(sctl_amd_op* op, int64_t Nt, const void* r_trg);
+int sctl_amd_op_set_sources(sctl_amd_op* op, int64_t Ns, const void* r_src, const void* n_src);
+/* v_src[Ns*SrcDim] and v_trg[Nt*TrgDim] are HOST arrays.  accumulate != 0: v_trg += result (GenericKernel::Eval,
+ * generic-kernel.txx:184); accumulate == 0: v_trg = result (ParticleFMM::EvalDirect, fmm-wrapper.txx:501-502). */
+int sctl_amd_op_eval(sctl_amd_op* op, const void* v_src, void* v_trg, int accumulate, int digits, const void* ctx, int ctx_bytes);
+void sctl_amd_op_destroy(sctl_amd_op* op);
+
 /* ---- accounting (the reference's Profile::IncrementCounter(FLOP, Ns*Nt*FLOPS()), generic-kernel.txx:188) ---- */
 /* Process-wide counters, updated atomically by every eval / kernel_matrix call. */
 void sctl_amd_counters(int64_t* pair_interactions, int64_t* sctl_flops);

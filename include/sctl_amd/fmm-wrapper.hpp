@@ -15,7 +15,8 @@
 // (:504-558); here the "ranks" are the GPUs of DeviceSet: targets are block-partitioned with the same formula
 // (:507), sources are replicated to every GPU (they are O(N) data for O(N^2) work), and there is no
 // ring.  Kernel objects are type-erased into a small record {device kernel id, dims, context} instead of
-// aligned_new'ed copies with function pointers (:371-405).
+// aligned_new'ed copies with function pointers (:371-405).  Coordinates are kept ON the GPUs between evaluations
+// (sctl_amd_op_*), so the repeated Eval of an iterative solver moves only densities and potentials over PCIe.
 #ifndef SCTL_AMD_FMM_WRAPPER_HPP_
 #define SCTL_AMD_FMM_WRAPPER_HPP_
 
@@ -35,7 +36,9 @@ template <class Real, Integer DIM = 3> class ParticleFMM {
   ParticleFMM& operator=(const ParticleFMM&) = delete;
 
   ParticleFMM(const Comm& comm = Comm::Self()) : comm_(comm), digits_(10), have_fmm_ker_(false) { static_assert(DIM == 3, "only DIM = 3 kernels exist"); }
-  ~ParticleFMM() {}
+  ~ParticleFMM() {
+    for (auto& it : s2t_map_) it.second.Release();
+  }
 
   void SetComm(const Comm& comm) { comm_ = comm; }
   void SetAccuracy(Integer digits) { digits_ = digits; }
@@ -81,6 +84,7 @@ template <class Real, Integer DIM = 3> class ParticleFMM {
     SCTL_AMD_ASSERT_MSG(src_map_.find(src_name) != src_map_.end(), "Source name does not exists.");
     SCTL_AMD_ASSERT_MSG(trg_map_.find(trg_name) != trg_map_.end(), "Target name does not exists.");
     S2TData& data = s2t_map_[std::make_pair(src_name, trg_name)];   // replaces an existing entry
+    data.Release();
     data.dim_src = ker_s2t.SrcDim();
     data.dim_trg = ker_s2t.TrgDim();
     data.dim_normal = ker_s2t.NormalDim();
@@ -99,12 +103,16 @@ template <class Real, Integer DIM = 3> class ParticleFMM {
   void DeleteSrc(const std::string& name) {
     SCTL_AMD_ASSERT_MSG(src_map_.find(name) != src_map_.end(), "Source name does not exist.");
     src_map_.erase(name);
-    for (auto it = s2t_map_.begin(); it != s2t_map_.end();) it = (it->first.first == name) ? s2t_map_.erase(it) : std::next(it);
+    for (auto it = s2t_map_.begin(); it != s2t_map_.end();) {
+      if (it->first.first == name) { it->second.Release(); it = s2t_map_.erase(it); } else ++it;
+    }
   }
   void DeleteTrg(const std::string& name) {
     SCTL_AMD_ASSERT_MSG(trg_map_.find(name) != trg_map_.end(), "Target name does not exist.");
     trg_map_.erase(name);
-    for (auto it = s2t_map_.begin(); it != s2t_map_.end();) it = (it->first.second == name) ? s2t_map_.erase(it) : std::next(it);
+    for (auto it = s2t_map_.begin(); it != s2t_map_.end();) {
+      if (it->first.second == name) { it->second.Release(); it = s2t_map_.erase(it); } else ++it;
+    }
   }
 
   void SetSrcCoord(const std::string& name, const Vector<Real>& src_coord, const Vector<Real>& src_normal = Vector<Real>()) {
@@ -112,6 +120,7 @@ template <class Real, Integer DIM = 3> class ParticleFMM {
     SrcData& data = src_map_[name];
     data.X = src_coord;
     data.Xn = src_normal;
+    for (auto& it : s2t_map_) if (it.first.first == name) it.second.src_dirty = true;   // re-upload at the next Eval
   }
   void SetSrcDensity(const std::string& name, const Vector<Real>& src_density) {
     SCTL_AMD_ASSERT_MSG(src_map_.find(name) != src_map_.end(), "Target name does not exist.");
@@ -120,6 +129,7 @@ template <class Real, Integer DIM = 3> class ParticleFMM {
   void SetTrgCoord(const std::string& name, const Vector<Real>& trg_coord) {
     SCTL_AMD_ASSERT_MSG(trg_map_.find(name) != trg_map_.end(), "Target name does not exist.");
     trg_map_[name].X = trg_coord;
+    for (auto& it : s2t_map_) if (it.first.second == name) it.second.trg_dirty = true;
   }
 
   void Eval(Vector<Real>& U, const std::string& trg_name) const {
@@ -150,11 +160,24 @@ template <class Real, Integer DIM = 3> class ParticleFMM {
       SCTL_AMD_ASSERT(src_data.F.Dim() == Ns * SrcDim);
       SCTL_AMD_ASSERT(!NorDim || src_data.Xn.Dim() == Ns * NorDim);
       SCTL_AMD_ASSERT(s2t.dim_trg == TrgDim && s2t.dim_src == SrcDim && s2t.dim_normal == NorDim);
-      // accumulates into U: successive source types add up (fmm-wrapper.txx:557 with a right-sized U)
-      const int rc = sctl_amd_eval_host_multi(s2t.kernel_id, RealTag<Real>::value, Nt, Ns, Xt.begin(), src_data.X.begin(),
-                                              NorDim ? src_data.Xn.begin() : nullptr, src_data.F.begin(), U.begin(), (int)digits_,
-                                              s2t.ctx_bytes ? s2t.ctx.data() : nullptr, s2t.ctx_bytes, devs.data(), (int)devs.size());
-      CheckStatus(rc, "sctl_amd_eval_host_multi");
+      // Coordinates live on the GPUs between evaluations (sctl_amd_op_*): they are uploaded again only after
+      // SetSrcCoord / SetTrgCoord or a change of the device set; an Eval moves the density down and the potential up.
+      if (!s2t.op || s2t.op_devs != devs) {
+        s2t.Release();
+        CheckStatus(sctl_amd_op_create(s2t.kernel_id, RealTag<Real>::value, devs.data(), (int)devs.size(), &s2t.op), "sctl_amd_op_create");
+        s2t.op_devs = devs;
+      }
+      if (s2t.trg_dirty) {
+        CheckStatus(sctl_amd_op_set_targets(s2t.op, Nt, Xt.begin()), "sctl_amd_op_set_targets");
+        s2t.trg_dirty = false;
+      }
+      if (s2t.src_dirty) {
+        CheckStatus(sctl_amd_op_set_sources(s2t.op, Ns, src_data.X.begin(), NorDim ? src_data.Xn.begin() : nullptr), "sctl_amd_op_set_sources");
+        s2t.src_dirty = false;
+      }
+      // accumulates into the zeroed U: successive source types add up (fmm-wrapper.txx:557 with a right-sized U)
+      const int rc = sctl_amd_op_eval(s2t.op, src_data.F.begin(), U.begin(), 1, (int)digits_, s2t.ctx_bytes ? s2t.ctx.data() : nullptr, s2t.ctx_bytes);
+      CheckStatus(rc, "sctl_amd_op_eval");
     }
   }
 
@@ -162,7 +185,21 @@ template <class Real, Integer DIM = 3> class ParticleFMM {
   struct FMMKernels { Integer dim_mul_ch, dim_mul_eq, dim_loc_ch, dim_loc_eq; };
   struct SrcData { Vector<Real> X, Xn, F; Integer dim_src, dim_mul_ch, dim_loc_ch, dim_normal; };
   struct TrgData { Vector<Real> X; Integer dim_trg, dim_mul_eq, dim_loc_eq; };
-  struct S2TData { Integer dim_src, dim_trg, dim_normal; int kernel_id; int ctx_bytes; std::vector<char> ctx; };
+  struct S2TData {
+    Integer dim_src, dim_trg, dim_normal;
+    int kernel_id;
+    int ctx_bytes;
+    std::vector<char> ctx;
+    // device-resident state (lazily created by EvalDirect, which is const like the reference's)
+    mutable sctl_amd_op* op = nullptr;
+    mutable std::vector<int> op_devs;
+    mutable bool src_dirty = true, trg_dirty = true;
+    void Release() const {
+      if (op) sctl_amd_op_destroy(op);
+      op = nullptr;
+      src_dirty = trg_dirty = true;
+    }
+  };
 
   // fmm-wrapper.txx:568-604
   void CheckKernelDims() const {

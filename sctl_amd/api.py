@@ -23,7 +23,8 @@ KERNEL_NAMES = ["Laplace3D-FxU", "Laplace3D-DxU", "Laplace3D-FxdU", "Stokes3D-Fx
 SYMBOLS = ["sctl_amd_version", "sctl_amd_last_error", "sctl_amd_device_count", "sctl_amd_kernel_id", "sctl_amd_kernel_name",
            "sctl_amd_kernel_info", "sctl_amd_flops_per_pair", "sctl_amd_eval_device", "sctl_amd_eval_host", "sctl_amd_eval_host_multi",
            "sctl_amd_kernel_matrix_device", "sctl_amd_kernel_matrix_host", "sctl_amd_counters", "sctl_amd_reset_counters",
-           "sctl_amd_eval_plan", "sctl_amd_eval_path"]
+           "sctl_amd_eval_plan", "sctl_amd_eval_path", "sctl_amd_op_create", "sctl_amd_op_set_targets",
+           "sctl_amd_op_set_sources", "sctl_amd_op_eval", "sctl_amd_op_destroy"]
 
 
 class SctlAmdError(RuntimeError):
@@ -60,6 +61,12 @@ def lib():
     L.sctl_amd_reset_counters.restype = None
     L.sctl_amd_eval_plan.argtypes = [ci, ci, i64, i64, ci, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(i64), C.POINTER(i64)]
     L.sctl_amd_eval_path.argtypes = [ci, ci, i64, i64]
+    L.sctl_amd_op_create.argtypes = [ci, ci, C.POINTER(C.c_int), ci, C.POINTER(vp)]
+    L.sctl_amd_op_set_targets.argtypes = [vp, i64, vp]
+    L.sctl_amd_op_set_sources.argtypes = [vp, i64, vp, vp]
+    L.sctl_amd_op_eval.argtypes = [vp, vp, vp, ci, ci, vp, ci]
+    L.sctl_amd_op_destroy.argtypes = [vp]
+    L.sctl_amd_op_destroy.restype = None
     _LIB = L
     return L
 
@@ -268,3 +275,46 @@ class GenericKernel:
         if isinstance(Xt, np.ndarray):
             return kernel_matrix_host(self._info["id"], Xt, Xs, Xn, digits, self._ctx, **kw)
         return kernel_matrix_device(self._info["id"], Xt, Xs, Xn, M, digits, self._ctx, **kw)
+
+
+class DirectOp:
+    """Device-resident operator (sctl_amd_op_*): coordinates are uploaded once, each eval() moves only density and
+    potential.  The Python face of what ParticleFMM keeps between SetSrcCoord/SetTrgCoord and repeated Eval calls."""
+
+    def __init__(self, name, dtype=np.float64, devices=(0,), ctx=None):
+        self.info = kernel_info(name)
+        self.dtype = np.dtype(dtype)
+        self.real = _real_of(dtype)
+        self.ctx = ctx
+        self.Nt = self.Ns = 0
+        self._h = C.c_void_p()
+        devs = (C.c_int * len(devices))(*devices)
+        _check(lib().sctl_amd_op_create(self.info["id"], self.real, devs, len(devices), C.byref(self._h)), "op_create")
+
+    def set_targets(self, r_trg):
+        self.Nt = r_trg.size // 3
+        _check(lib().sctl_amd_op_set_targets(self._h, self.Nt, _np_ptr(r_trg, self.dtype, self.Nt * 3, "r_trg")), "op_set_targets")
+
+    def set_sources(self, r_src, n_src=None):
+        self.Ns = r_src.size // 3
+        _check(lib().sctl_amd_op_set_sources(self._h, self.Ns, _np_ptr(r_src, self.dtype, self.Ns * 3, "r_src"),
+                                             _np_ptr(n_src, self.dtype, self.Ns * self.info["nd"], "n_src")), "op_set_sources")
+
+    def eval(self, v_src, v_trg=None, accumulate=False, digits=-1):
+        if v_trg is None or v_trg.size != self.Nt * self.info["k1"]:
+            v_trg = np.zeros(self.Nt * self.info["k1"], dtype=self.dtype)
+        keep, cp, cb = _ctx_blob(self.info, self.ctx)
+        _check(lib().sctl_amd_op_eval(self._h, _np_ptr(v_src, self.dtype, self.Ns * self.info["k0"], "v_src"),
+                                      _np_ptr(v_trg, self.dtype, self.Nt * self.info["k1"], "v_trg"), 1 if accumulate else 0, digits, cp, cb), "op_eval")
+        return v_trg
+
+    def close(self):
+        if self._h:
+            lib().sctl_amd_op_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

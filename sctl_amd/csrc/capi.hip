@@ -4,6 +4,8 @@
 #include "launch.hpp"
 
 #include <atomic>
+#include <functional>
+#include <memory>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -156,6 +158,7 @@ template <class R>
 int eval_device_t(const KernelEntry& k, int real, int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* xn, const R* f, R* v, int digits,
                   const void* ctx, hipStream_t st) {
   if (Nt == 0 || Ns == 0) return SCTL_AMD_OK;   // nothing to add (generic-kernel.txx:153-186 degenerates to v_trg += 0)
+  (void)hipGetLastError();                      // drop a stale error of an earlier, unrelated runtime call on this thread
   const Plan p = make_plan(k, real, Nt, Ns);
   const int mode = mode_for(real, digits);
   if (use_centered(k, real, Nt, Ns)) return eval_centered_or_fail<R>(k, Nt, Ns, xt, xs, f, v, mode, p, st);
@@ -186,6 +189,7 @@ template <class R>
 int matrix_device_t(const KernelEntry& k, int real, int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* xn, R* M, int digits,
                     const void* ctx, hipStream_t st) {
   if (Nt == 0 || Ns == 0) return SCTL_AMD_OK;
+  (void)hipGetLastError();
   const int mode = mode_for(real, digits);
   const dim3 grid((unsigned)((Nt + kBlock - 1) / kBlock), (unsigned)(Ns < 65535 ? Ns : 65535));
   pick_matrix<R>(k, mode)(Nt, Ns, xt, xs, xn, M, (R)k.scale, make_ctx(k, ctx), grid, st);
@@ -206,6 +210,77 @@ struct StreamGuard {
   ~StreamGuard() { if (s) (void)hipStreamDestroy(s); }
 };
 
+// Pinned (hipHostMalloc) staging memory for every host<->device transfer of the host-pointer entry points.
+// Why not hipMemcpyAsync straight from the caller's pageable arrays: callers reuse their arrays (SCTL keeps one density
+// vector and rewrites it every solver iteration), and with ROCm 7.2 on this platform an H2D copy from a pageable buffer
+// whose CONTENTS changed since the previous copy from the SAME address delivered the old contents about once per
+// thousand transfers (tools/dbg stress: 3-4 of 3000 with one reused host buffer, 0 of 3000 with alternating buffers,
+// with or without SDMA, with hipMemcpy as well as hipMemcpyAsync).  A CPU memcpy into pinned memory plus a DMA from
+// there costs ~1.5 % at 2^20 points and removes the hazard.
+struct PinnedBuf {
+  char* p = nullptr;
+  size_t cap = 0, used = 0;
+  ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+  hipError_t reserve(size_t bytes) {   // discards the contents; call before the first take() of a transfer batch
+    used = 0;
+    if (bytes <= cap) return hipSuccess;
+    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+    hipError_t e = hipHostMalloc((void**)&p, bytes, hipHostMallocPortable);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+  }
+  char* take(size_t bytes) {           // 256-byte aligned slice
+    char* q = p + used;
+    used += (bytes + 255) & ~(size_t)255;
+    return q;
+  }
+};
+inline size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// host array -> pinned slice -> device (async on st); the slice must stay untouched until st is synchronised
+hipError_t upload(void* dst, const void* src, size_t bytes, PinnedBuf& stage, hipStream_t st) {
+  if (!bytes) return hipSuccess;
+  char* q = stage.take(bytes);
+  std::memcpy(q, src, bytes);
+  return hipMemcpyAsync(dst, q, bytes, hipMemcpyHostToDevice, st);
+}
+
+// grow-only device buffer and the per-(thread, device) cache of the one-shot host entry
+struct CachedDevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 8);
+    if (e == hipSuccess) cap = bytes ? bytes : 8;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+struct DevRef { CachedDevBuf& b; void* p_() const { return b.p; } };
+struct HostSlot {
+  int device = -1;
+  StreamGuard st;
+  CachedDevBuf buf[5];
+  PinnedBuf stage;
+  void trim(size_t keep) {
+    size_t tot = stage.cap;
+    for (auto& b : buf) tot += b.cap;
+    if (tot <= keep) return;
+    for (auto& b : buf) b.release();
+    if (stage.p) { (void)hipHostFree(stage.p); stage.p = nullptr; stage.cap = 0; }
+  }
+  ~HostSlot() { for (auto& b : buf) b.release(); }
+};
+HostSlot& host_slot(int device) {
+  static thread_local std::vector<std::unique_ptr<HostSlot>> slots;
+  for (auto& s : slots) if (s->device == device) return *s;
+  slots.emplace_back(new HostSlot);
+  slots.back()->device = device;
+  return *slots.back();
+}
+
 // one GPU: targets [t0, t1) of the host arrays, all sources
 int eval_host_slab(const KernelEntry& k, int real, int64_t t0, int64_t t1, int64_t Ns, const void* r_trg, const void* r_src, const void* n_src,
                    const void* v_src, void* v_trg, int digits, const void* ctx, int device) {
@@ -213,44 +288,96 @@ int eval_host_slab(const KernelEntry& k, int real, int64_t t0, int64_t t1, int64
   const int64_t Nt = t1 - t0;
   if (Nt <= 0 || Ns <= 0) return SCTL_AMD_OK;
   HIP_TRY(hipSetDevice(device));
-  StreamGuard st;
-  HIP_TRY(hipStreamCreateWithFlags(&st.s, hipStreamNonBlocking));
-  DevBuf dxt, dxs, dxn, df, dv;
-  HIP_TRY(dxt.alloc((size_t)Nt * 3 * rs));
-  HIP_TRY(dxs.alloc((size_t)Ns * 3 * rs));
-  HIP_TRY(dxn.alloc((size_t)Ns * k.nd * rs));
-  HIP_TRY(df.alloc((size_t)Ns * k.k0 * rs));
-  HIP_TRY(dv.alloc((size_t)Nt * k.k1 * rs));
-  HIP_TRY(hipMemcpyAsync(dxt.p, (const char*)r_trg + (size_t)t0 * 3 * rs, (size_t)Nt * 3 * rs, hipMemcpyHostToDevice, st.s));
-  HIP_TRY(hipMemcpyAsync(dxs.p, r_src, (size_t)Ns * 3 * rs, hipMemcpyHostToDevice, st.s));
-  if (k.nd) HIP_TRY(hipMemcpyAsync(dxn.p, n_src, (size_t)Ns * k.nd * rs, hipMemcpyHostToDevice, st.s));
-  HIP_TRY(hipMemcpyAsync(df.p, v_src, (size_t)Ns * k.k0 * rs, hipMemcpyHostToDevice, st.s));
-  HIP_TRY(hipMemsetAsync(dv.p, 0, (size_t)Nt * k.k1 * rs, st.s));
+  // Stream, device buffers and pinned staging are kept per (calling thread, device) between calls: at 2^14 points the
+  // five hipMalloc/hipFree pairs and the stream creation cost 2.9 of the 3.1 ms a call took.  Anything above 64 MB is
+  // released again when the call returns.
+  HostSlot& hs = host_slot(device);
+  if (!hs.st.s) HIP_TRY(hipStreamCreateWithFlags(&hs.st.s, hipStreamNonBlocking));
+  StreamGuard& st = hs.st;
+  PinnedBuf& stage = hs.stage;
+  struct Release { HostSlot& h; ~Release() { h.trim((size_t)64 << 20); } } release{hs};
+  DevRef dxt{hs.buf[0]}, dxs{hs.buf[1]}, dxn{hs.buf[2]}, df{hs.buf[3]}, dv{hs.buf[4]};
+  HIP_TRY(hs.buf[0].reserve((size_t)Nt * 3 * rs));
+  HIP_TRY(hs.buf[1].reserve((size_t)Ns * 3 * rs));
+  HIP_TRY(hs.buf[2].reserve((size_t)Ns * k.nd * rs));
+  HIP_TRY(hs.buf[3].reserve((size_t)Ns * k.k0 * rs));
+  HIP_TRY(hs.buf[4].reserve((size_t)Nt * k.k1 * rs));
+  const size_t b_xt = (size_t)Nt * 3 * rs, b_xs = (size_t)Ns * 3 * rs, b_xn = (size_t)Ns * k.nd * rs, b_f = (size_t)Ns * k.k0 * rs,
+               b_v = (size_t)Nt * k.k1 * rs;
+  HIP_TRY(stage.reserve(pad256(b_xt) + pad256(b_xs) + pad256(b_xn) + pad256(b_f) + pad256(b_v)));
+  HIP_TRY(upload(dxt.b.p, (const char*)r_trg + (size_t)t0 * 3 * rs, b_xt, stage, st.s));
+  HIP_TRY(upload(dxs.b.p, r_src, b_xs, stage, st.s));
+  if (k.nd) HIP_TRY(upload(dxn.b.p, n_src, b_xn, stage, st.s));
+  HIP_TRY(upload(df.b.p, v_src, b_f, stage, st.s));
+  HIP_TRY(hipMemsetAsync(dv.b.p, 0, b_v, st.s));
   int rc;
   if (real == SCTL_AMD_F64)
-    rc = eval_device_t<double>(k, real, Nt, Ns, (const double*)dxt.p, (const double*)dxs.p, (const double*)dxn.p, (const double*)df.p, (double*)dv.p,
+    rc = eval_device_t<double>(k, real, Nt, Ns, (const double*)dxt.b.p, (const double*)dxs.b.p, (const double*)dxn.b.p, (const double*)df.b.p, (double*)dv.b.p,
                                digits, ctx, st.s);
   else
-    rc = eval_device_t<float>(k, real, Nt, Ns, (const float*)dxt.p, (const float*)dxs.p, (const float*)dxn.p, (const float*)df.p, (float*)dv.p, digits,
+    rc = eval_device_t<float>(k, real, Nt, Ns, (const float*)dxt.b.p, (const float*)dxs.b.p, (const float*)dxn.b.p, (const float*)df.b.p, (float*)dv.b.p, digits,
                               ctx, st.s);
   if (rc != SCTL_AMD_OK) return rc;
-  std::vector<char> out((size_t)Nt * k.k1 * rs);
-  HIP_TRY(hipMemcpyAsync(out.data(), dv.p, out.size(), hipMemcpyDeviceToHost, st.s));
+  char* out = stage.take(b_v);
+  HIP_TRY(hipMemcpyAsync(out, dv.b.p, b_v, hipMemcpyDeviceToHost, st.s));
   HIP_TRY(hipStreamSynchronize(st.s));
   // v_trg += device result (generic-kernel.txx:182-186; the scale factor was applied on the device)
   const int64_t n = Nt * k.k1;
   if (real == SCTL_AMD_F64) {
     double* dst = (double*)v_trg + t0 * k.k1;
-    const double* src = (const double*)out.data();
+    const double* src = (const double*)out;
     for (int64_t i = 0; i < n; i++) dst[i] += src[i];
   } else {
     float* dst = (float*)v_trg + t0 * k.k1;
-    const float* src = (const float*)out.data();
+    const float* src = (const float*)out;
     for (int64_t i = 0; i < n; i++) dst[i] += src[i];
   }
   return SCTL_AMD_OK;
 }
 
+
+// ---- device-resident operator (sctl_amd_op_*) ----------------------------------------------------------------
+struct OpDevice {
+  int device = 0;
+  hipStream_t st = nullptr;
+  int64_t t0 = 0, t1 = 0;                 // target slab of this device
+  void *xt = nullptr, *xs = nullptr, *xn = nullptr, *f = nullptr, *v = nullptr;
+  size_t cap_xt = 0, cap_xs = 0, cap_xn = 0, cap_f = 0, cap_v = 0;
+  PinnedBuf stage;                        // pinned staging for uploads and for the slab of the potential
+};
+
+hipError_t grow(void** p, size_t* cap, size_t bytes) {
+  if (bytes <= *cap) return hipSuccess;
+  if (*p) { hipError_t e = hipFree(*p); if (e != hipSuccess) return e; *p = nullptr; *cap = 0; }
+  hipError_t e = hipMalloc(p, bytes);
+  if (e == hipSuccess) *cap = bytes;
+  return e;
+}
+}  // namespace
+}  // namespace sctl_amd
+
+struct sctl_amd_op {
+  const sctl_amd::KernelEntry* k = nullptr;
+  int real = 0;
+  int64_t Nt = 0, Ns = 0;
+  std::vector<sctl_amd::OpDevice> devs;
+};
+
+namespace sctl_amd {
+namespace {
+
+int op_for_each_device(sctl_amd_op* op, const std::function<int(OpDevice&)>& fn) {
+  const int n = (int)op->devs.size();
+  if (n == 1) return fn(op->devs[0]);
+  std::vector<int> rcs(n, SCTL_AMD_OK);
+  std::vector<std::string> msgs(n);
+  std::vector<std::thread> th;
+  for (int g = 0; g < n; g++) th.emplace_back([&, g] { rcs[g] = fn(op->devs[g]); if (rcs[g]) msgs[g] = g_err; });
+  for (auto& t : th) t.join();
+  for (int g = 0; g < n; g++)
+    if (rcs[g]) return fail(rcs[g], "device " + std::to_string(op->devs[g].device) + ": " + msgs[g]);
+  return SCTL_AMD_OK;
+}
 }  // namespace
 }  // namespace sctl_amd
 
@@ -374,14 +501,129 @@ int sctl_amd_kernel_matrix_host(int kernel, int real, int64_t Nt, int64_t Ns, co
   HIP_TRY(dxs.alloc((size_t)Ns * 3 * rs));
   HIP_TRY(dxn.alloc((size_t)Ns * k->nd * rs));
   HIP_TRY(dm.alloc(mbytes));
-  HIP_TRY(hipMemcpyAsync(dxt.p, r_trg, (size_t)Nt * 3 * rs, hipMemcpyHostToDevice, st.s));
-  HIP_TRY(hipMemcpyAsync(dxs.p, r_src, (size_t)Ns * 3 * rs, hipMemcpyHostToDevice, st.s));
-  if (k->nd) HIP_TRY(hipMemcpyAsync(dxn.p, n_src, (size_t)Ns * k->nd * rs, hipMemcpyHostToDevice, st.s));
+  static thread_local PinnedBuf stage;
+  HIP_TRY(stage.reserve(pad256((size_t)Nt * 3 * rs) + pad256((size_t)Ns * 3 * rs) + pad256((size_t)Ns * k->nd * rs)));
+  HIP_TRY(upload(dxt.p, r_trg, (size_t)Nt * 3 * rs, stage, st.s));
+  HIP_TRY(upload(dxs.p, r_src, (size_t)Ns * 3 * rs, stage, st.s));
+  if (k->nd) HIP_TRY(upload(dxn.p, n_src, (size_t)Ns * k->nd * rs, stage, st.s));
   rc = sctl_amd_kernel_matrix_device(kernel, real, Nt, Ns, dxt.p, dxs.p, dxn.p, dm.p, digits, ctx, ctx_bytes, st.s);
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(M, dm.p, mbytes, hipMemcpyDeviceToHost, st.s));
   HIP_TRY(hipStreamSynchronize(st.s));
   return SCTL_AMD_OK;
+}
+
+
+int sctl_amd_op_create(int kernel, int real, const int* devices, int n_devices, sctl_amd_op** out) {
+  const KernelEntry* k = registry(kernel);
+  if (!k) return fail(SCTL_AMD_ERR_UNKNOWN_KERNEL, "unknown kernel id");
+  if (real != SCTL_AMD_F64 && real != SCTL_AMD_F32) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "real must be SCTL_AMD_F64 or SCTL_AMD_F32");
+  if (!out || n_devices <= 0) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "null handle pointer or no devices");
+  const int avail = device_count_quiet();
+  if (avail <= 0) return fail(SCTL_AMD_ERR_NO_DEVICE, "no HIP device: libsctl_amd has no CPU fallback");
+  sctl_amd_op* op = new sctl_amd_op;
+  op->k = k; op->real = real;
+  op->devs.resize(n_devices);
+  for (int g = 0; g < n_devices; g++) {
+    OpDevice& d = op->devs[g];
+    d.device = devices ? devices[g] : g;
+    if (d.device < 0 || d.device >= avail) { sctl_amd_op_destroy(op); return fail(SCTL_AMD_ERR_NO_DEVICE, "device index out of range"); }
+    if (hipSetDevice(d.device) != hipSuccess || hipStreamCreateWithFlags(&d.st, hipStreamNonBlocking) != hipSuccess) {
+      sctl_amd_op_destroy(op);
+      return fail(SCTL_AMD_ERR_HIP, "cannot create a stream on device " + std::to_string(d.device));
+    }
+  }
+  *out = op;
+  return SCTL_AMD_OK;
+}
+
+void sctl_amd_op_destroy(sctl_amd_op* op) {
+  if (!op) return;
+  const int avail = device_count_quiet();
+  for (OpDevice& d : op->devs) {
+    if (d.device < 0 || d.device >= avail || !d.st) continue;   // never initialised (create failed on this entry)
+    if (hipSetDevice(d.device) != hipSuccess) { (void)hipGetLastError(); continue; }
+    for (void* p : {d.xt, d.xs, d.xn, d.f, d.v})
+      if (p) (void)hipFree(p);
+    if (d.st) (void)hipStreamDestroy(d.st);
+  }
+  delete op;
+}
+
+int sctl_amd_op_set_targets(sctl_amd_op* op, int64_t Nt, const void* r_trg) {
+  if (!op || Nt < 0 || (Nt > 0 && !r_trg)) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "bad target arguments");
+  const size_t rs = (op->real == SCTL_AMD_F64) ? 8 : 4;
+  const int G = (int)op->devs.size();
+  op->Nt = Nt;
+  int g = 0;
+  for (OpDevice& d : op->devs) { d.t0 = Nt * g / G; d.t1 = Nt * (g + 1) / G; g++; }   // fmm-wrapper.txx:507
+  return op_for_each_device(op, [&](OpDevice& d) -> int {
+    const size_t bytes = (size_t)(d.t1 - d.t0) * 3 * rs;
+    HIP_TRY(hipSetDevice(d.device));
+    HIP_TRY(grow(&d.xt, &d.cap_xt, bytes));
+    HIP_TRY(d.stage.reserve(pad256(bytes)));
+    HIP_TRY(upload(d.xt, (const char*)r_trg + (size_t)d.t0 * 3 * rs, bytes, d.stage, d.st));
+    HIP_TRY(hipStreamSynchronize(d.st));
+    return SCTL_AMD_OK;
+  });
+}
+
+int sctl_amd_op_set_sources(sctl_amd_op* op, int64_t Ns, const void* r_src, const void* n_src) {
+  if (!op || Ns < 0 || (Ns > 0 && !r_src)) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "bad source arguments");
+  if (Ns > 0 && op->k->nd > 0 && !n_src) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, std::string(op->k->name) + " needs source normals (n_src is null)");
+  const size_t rs = (op->real == SCTL_AMD_F64) ? 8 : 4;
+  op->Ns = Ns;
+  return op_for_each_device(op, [&](OpDevice& d) -> int {
+    HIP_TRY(hipSetDevice(d.device));
+    HIP_TRY(grow(&d.xs, &d.cap_xs, (size_t)Ns * 3 * rs));
+    HIP_TRY(grow(&d.xn, &d.cap_xn, (size_t)Ns * op->k->nd * rs));
+    HIP_TRY(d.stage.reserve(pad256((size_t)Ns * 3 * rs) + pad256((size_t)Ns * op->k->nd * rs)));
+    HIP_TRY(upload(d.xs, r_src, (size_t)Ns * 3 * rs, d.stage, d.st));
+    if (op->k->nd) HIP_TRY(upload(d.xn, n_src, (size_t)Ns * op->k->nd * rs, d.stage, d.st));
+    HIP_TRY(hipStreamSynchronize(d.st));
+    return SCTL_AMD_OK;
+  });
+}
+
+int sctl_amd_op_eval(sctl_amd_op* op, const void* v_src, void* v_trg, int accumulate, int digits, const void* ctx, int ctx_bytes) {
+  if (!op) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "null handle");
+  const KernelEntry& k = *op->k;
+  if (k.ctx_bytes != 0 && (ctx_bytes != k.ctx_bytes || !ctx))
+    return fail(SCTL_AMD_ERR_BAD_CONTEXT, std::string(k.name) + " needs a context blob of " + std::to_string(k.ctx_bytes) + " bytes");
+  if ((op->Ns > 0 && !v_src) || (op->Nt > 0 && !v_trg)) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "null density or potential array");
+  const size_t rs = (op->real == SCTL_AMD_F64) ? 8 : 4;
+  const int64_t Ns = op->Ns;
+  return op_for_each_device(op, [&](OpDevice& d) -> int {
+    const int64_t nt = d.t1 - d.t0;
+    const size_t vbytes = (size_t)nt * k.k1 * rs;
+    if (nt == 0) return SCTL_AMD_OK;
+    HIP_TRY(hipSetDevice(d.device));
+    HIP_TRY(grow(&d.f, &d.cap_f, (size_t)Ns * k.k0 * rs));
+    HIP_TRY(grow(&d.v, &d.cap_v, vbytes));
+    HIP_TRY(d.stage.reserve(pad256((size_t)Ns * k.k0 * rs) + pad256(vbytes)));
+    HIP_TRY(upload(d.f, v_src, (size_t)Ns * k.k0 * rs, d.stage, d.st));
+    HIP_TRY(hipMemsetAsync(d.v, 0, vbytes, d.st));
+    int rc;
+    if (op->real == SCTL_AMD_F64)
+      rc = eval_device_t<double>(k, op->real, nt, Ns, (const double*)d.xt, (const double*)d.xs, (const double*)d.xn, (const double*)d.f, (double*)d.v,
+                                 digits, ctx, d.st);
+    else
+      rc = eval_device_t<float>(k, op->real, nt, Ns, (const float*)d.xt, (const float*)d.xs, (const float*)d.xn, (const float*)d.f, (float*)d.v, digits,
+                                ctx, d.st);
+    if (rc) return rc;
+    char* dst = (char*)v_trg + (size_t)d.t0 * k.k1 * rs;
+    const char* out = d.stage.take(vbytes);
+    HIP_TRY(hipMemcpyAsync((void*)out, d.v, vbytes, hipMemcpyDeviceToHost, d.st));
+    HIP_TRY(hipStreamSynchronize(d.st));
+    if (!accumulate) {
+      std::memcpy(dst, out, vbytes);
+      return SCTL_AMD_OK;
+    }
+    const int64_t n = nt * k.k1;
+    if (op->real == SCTL_AMD_F64) { double* o = (double*)dst; const double* s = (const double*)out; for (int64_t i = 0; i < n; i++) o[i] += s[i]; }
+    else { float* o = (float*)dst; const float* s = (const float*)out; for (int64_t i = 0; i < n; i++) o[i] += s[i]; }
+    return SCTL_AMD_OK;
+  });
 }
 
 void sctl_amd_counters(int64_t* pair_interactions, int64_t* sctl_flops) {

@@ -32,6 +32,11 @@ template <class R> __device__ __forceinline__ R wave_max(R v) {
   return v;
 }
 
+// wave-uniform double -> scalar registers (frees two VGPRs per value in a kernel that is VGPR-limited to 4 waves/SIMD)
+__device__ __forceinline__ double uniform_(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
 // One wave64 per workgroup: the unit that shares a centre is 64*T Morton-consecutive targets (128 for T = 2), which keeps
 // the cluster radius — and with it the fraction of near sources (3.5 % at 2^20 uniform points, vs 9 % for 512 targets) —
 // small and evens out the work per SIMD (32 independent workgroups per CU).  Each wave stages its own 64-source tiles;
@@ -41,6 +46,7 @@ constexpr int kWaveTile = 64;    // sources per LDS tile
 constexpr int kNearCap = 128;    // capacity of the per-wave list of pending near sources
 
 // a.xt: Morton-sorted targets; a.v_trg / a.partial: indexed like a.xt (the caller scatters back); fp64 only.
+// (asking the compiler for 5-6 waves/SIMD instead of the 4 its 118 VGPRs allow costs 1-3 %: measured 464-471 vs 458 ms)
 template <int MODE, int T, int UNR = 4>
 __global__ void __launch_bounds__(kWaveBlock) laplace_fxu_centered_kernel(const EvalArgs<double> a) {
   using R = double;
@@ -73,7 +79,7 @@ __global__ void __launch_bounds__(kWaveBlock) laplace_fxu_centered_kernel(const 
       }
     }
 #pragma unroll
-    for (int k = 0; k < 3; k++) c[k] = 0.5 * wave_min(lo[k]) + 0.5 * wave_max(hi[k]);
+    for (int k = 0; k < 3; k++) c[k] = uniform_(0.5 * wave_min(lo[k]) + 0.5 * wave_max(hi[k]));
   }
   R m2x[T][3], tt[T], rt2 = 0;
 #pragma unroll
@@ -84,7 +90,7 @@ __global__ void __launch_bounds__(kWaveBlock) laplace_fxu_centered_kernel(const 
 #pragma unroll
     for (int k = 0; k < 3; k++) m2x[j][k] = -2.0 * p[k];
   }
-  rt2 = wave_max(rt2);
+  rt2 = uniform_(wave_max(rt2));
   const R near_r2 = a.ctx.v[0] * rt2;   // ctx.v[0] = kNearFactor2; NaN coordinates fail every comparison => "near" => exact path
 
   R acc[T];
@@ -116,13 +122,21 @@ __global__ void __launch_bounds__(kWaveBlock) laplace_fxu_centered_kernel(const 
       if (lane == 0) { nearA[nn * 2] = V{c[0] + far_off, c[1]}; nearA[nn * 2 + 1] = V{c[2], 0.0}; }
       __syncthreads();
     }
+    R xo[T][3];   // the original target coordinates are needed only here: reloaded (L2 hit) rather than kept in 12 VGPRs
+#pragma unroll
+    for (int j = 0; j < T; j++) {
+      int64_t t = tbase + j * kWaveBlock + lane;
+      if (t >= a.Nt) t = a.Nt - 1;
+#pragma unroll
+      for (int k = 0; k < 3; k++) xo[j][k] = a.xt[t * 3 + k];
+    }
     for (int s = 0; s < nn; s += 2) {
 #pragma unroll
       for (int u = 0; u < 2; u++) {
         const V a0 = nearA[(s + u) * 2], a1 = nearA[(s + u) * 2 + 1];
 #pragma unroll
         for (int j = 0; j < T; j++) {
-          const R d[3] = {xt[j][0] - a0[0], xt[j][1] - a0[1], xt[j][2] - a1[0]};
+          const R d[3] = {xo[j][0] - a0[0], xo[j][1] - a0[1], xo[j][2] - a1[0]};
           acc[j] = fma_(a1[1], rsqrt_masked<MODE, true>(len2(d), K.rsq), acc[j]);
         }
       }

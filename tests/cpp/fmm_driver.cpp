@@ -4,6 +4,8 @@
 //
 //   fmm_driver <N> <out_prefix>
 // writes <out_prefix>_dl.bin   : EvalDirect, Stokes double layer -> velocity (the reference test's setup)
+//        <out_prefix>_dl2.bin  : the same after SetSrcDensity(-2 x density) (coordinates stay on the GPU)
+//        <out_prefix>_dl3.bin  : the same after SetSrcCoord moved the sources
 //        <out_prefix>_sum.bin  : EvalDirect with TWO source types (single + double layer) into one target type
 //        <out_prefix>_acc.bin  : GenericKernel::Eval called twice into the same vector (accumulate semantics)
 //        <out_prefix>_mat.bin  : GenericKernel::KernelMatrix, 20 sources x 33 targets
@@ -63,6 +65,19 @@ int main(int argc, char** argv) {
     for (const auto& a : Uref) nrm = std::max<Real>(nrm, std::fabs(a));
     std::cout << "Maximum relative error: " << err / nrm << '\n';
     Uref.Write((out + "_dl.bin").c_str());
+
+    // an iterative solver's pattern: new density, same coordinates (only the density goes over PCIe) ...
+    dl_den *= (Real)-2;
+    fmm.SetSrcDensity("DoubleLayer", dl_den);
+    Vector<Real> U2;
+    fmm.Eval(U2, "Velocity");
+    U2.Write((out + "_dl2.bin").c_str());
+    // ... then moved sources (coordinates are uploaded again)
+    fmm.SetSrcCoord("DoubleLayer", sl_coord, dl_norml);
+    Vector<Real> U3;
+    fmm.Eval(U3, "Velocity");
+    U3.Write((out + "_dl3.bin").c_str());
+    fmm.SetSrcCoord("DoubleLayer", dl_coord, dl_norml);
 
     // a second source type into the same target type: potentials add up
     fmm.AddSrc("SingleLayer", kernel_sl, kernel_sl);

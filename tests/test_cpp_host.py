@@ -56,16 +56,18 @@ def test_particle_fmm_driver_matches_oracle(tmp_path, O):
     u_sl = O.eval("Stokes3D-FxU", xt, sl_x, None, sl_f)
     # SetAccuracy(10): at least 10 digits
     assert rel_l2(_read_vector(str(tmp_path / "o_dl.bin")), u_dl) < 1e-10
-    assert rel_l2(_read_vector(str(tmp_path / "o_sum.bin")), u_dl + u_sl) < 1e-10
+    assert rel_l2(_read_vector(str(tmp_path / "o_dl2.bin")), -2 * u_dl) < 1e-10          # new density, resident coordinates
+    assert rel_l2(_read_vector(str(tmp_path / "o_dl3.bin")), O.eval("Stokes3D-DxU", xt, sl_x, dl_n, -2 * dl_f)) < 1e-10   # moved sources
+    assert rel_l2(_read_vector(str(tmp_path / "o_sum.bin")), -2 * u_dl + u_sl) < 1e-10
     assert rel_l2(_read_vector(str(tmp_path / "o_acc.bin")), 2 * u_sl) < 1e-12
     M = _read_vector(str(tmp_path / "o_mat.bin")).reshape(60, 99)
     assert rel_l2(M, O.kernel_matrix("Stokes3D-DxU", xt[:99].copy(), dl_x[:60].copy(), dl_n[:60].copy())) < 1e-12
     u_h = O.eval("Helmholtz3D-FxU", xt, sl_x, None, sl_f[:2 * N].copy(), ctx=np.array([7.5, 0.3]))
     assert rel_l2(_read_vector(str(tmp_path / "o_helm.bin")), u_h) < 1e-12
-    # Eval x2 + EvalDirect, the two-source Eval (2 kernels), GenericKernel::Eval x2, Helmholtz, and the 33x20 operator;
+    # Eval x2 + EvalDirect, two re-evaluations, the two-source Eval (2 kernels), GenericKernel::Eval x2, Helmholtz, the 33x20 operator;
     # SCTL-convention flops = pairs * FLOPS() (generic-kernel.txx:188)
-    assert "pair interactions: %d " % (N * N * 8 + 33 * 20) in p.stdout
-    assert "flops: %d" % (N * N * (4 * 26 + 3 * 23 + 16) + 33 * 20 * 26) in p.stdout
+    assert "pair interactions: %d " % (N * N * 10 + 33 * 20) in p.stdout
+    assert "flops: %d" % (N * N * (6 * 26 + 3 * 23 + 16) + 33 * 20 * 26) in p.stdout
 
 
 FAR = [c for c in load_manifest()["cases"] if c["kind"] == "far_field"]

@@ -191,3 +191,58 @@ def test_counters_follow_reference_flop_accounting():
     sctl_amd.eval_host("Stokes3D-DxU", np.random.rand(30), np.random.rand(60), np.random.rand(60), np.random.rand(60))
     c = sctl_amd.counters()
     assert c["pair_interactions"] == 200 and c["sctl_flops"] == 200 * 26
+
+
+def test_device_resident_operator_handle(O):
+    """sctl_amd_op_*: coordinates uploaded once; evaluations with new densities, accumulate / overwrite, new sources, and
+    the target slabs of a multi-device list (the same GPU listed twice)."""
+    name = "Laplace3D-DxU"
+    info = sctl_amd.kernel_info(name)
+    rng = np.random.default_rng(17)
+    xt, xs, xn, f = _rng_inputs(rng, 3001, 2500, info, np.float64)
+    for devs in ((0,), (0, 0)):
+        op = sctl_amd.DirectOp(name, np.float64, devices=devs)
+        op.set_targets(xt)
+        op.set_sources(xs, xn)
+        u1 = op.eval(f)
+        assert rel_l2(u1, O.eval(name, xt, xs, xn, f)) < 1e-12
+        f2 = rng.random(f.size) - 0.5
+        u2 = op.eval(f2)                                    # overwrite semantics (EvalDirect)
+        assert rel_l2(u2, O.eval(name, xt, xs, xn, f2)) < 1e-12
+        u3 = op.eval(f, v_trg=u2.copy(), accumulate=True)   # accumulate semantics (GenericKernel::Eval)
+        assert rel_l2(u3, O.eval(name, xt, xs, xn, f) + u2) < 1e-12
+        xs2, xn2 = rng.random(900 * 3), rng.random(900 * 3) - 0.5
+        f3 = rng.random(900) - 0.5
+        op.set_sources(xs2, xn2)                            # fewer sources than before: buffers are reused
+        assert rel_l2(op.eval(f3), O.eval(name, xt, xs2, xn2, f3)) < 1e-12
+        op.set_targets(xt[:300].copy())
+        assert rel_l2(op.eval(f3), O.eval(name, xt[:300].copy(), xs2, xn2, f3)) < 1e-12
+        op.close()
+    with pytest.raises(sctl_amd.api.SctlAmdError):
+        sctl_amd.DirectOp(name, np.float64, devices=(0, 99))
+
+
+def test_reused_host_buffers_are_always_re_read(O):
+    """Callers rewrite their coordinate / density arrays in place between evaluations (SCTL keeps one density vector per
+    source type).  Every host entry must deliver the NEW contents: a plain hipMemcpyAsync from a reused pageable buffer
+    returned stale data about once per thousand transfers on this platform, which is why the library stages through pinned
+    memory (capi.hip: PinnedBuf)."""
+    name = "Stokes3D-DxU"
+    info = sctl_amd.kernel_info(name)
+    rng = np.random.default_rng(23)
+    N = 3000
+    xt, xa, na, fa = _rng_inputs(rng, N, N, info, np.float64)
+    xb, fb = rng.random(N * 3), rng.random(N * 3) - 0.5
+    ref = {(0, 0): O.eval(name, xt, xa, na, fa), (1, 0): O.eval(name, xt, xb, na, fa), (0, 1): O.eval(name, xt, xa, na, fb),
+           (1, 1): O.eval(name, xt, xb, na, fb)}
+    op = sctl_amd.DirectOp(name)
+    op.set_targets(xt)
+    buf, fbuf = xa.copy(), fa.copy()
+    for it in range(600):
+        ub, uf = it & 1, (it >> 1) & 1
+        buf[:] = xb if ub else xa
+        fbuf[:] = fb if uf else fa
+        op.set_sources(buf, na)
+        assert rel_l2(op.eval(fbuf), ref[(ub, uf)]) < 1e-12, it
+        assert rel_l2(sctl_amd.eval_host(name, xt, buf, na, fbuf), ref[(ub, uf)]) < 1e-12, it
+    op.close()
