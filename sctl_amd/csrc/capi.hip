@@ -16,8 +16,9 @@
 
 namespace sctl_amd {
 // centered.hip
-hipError_t eval_laplace_fxu_centered(int64_t Nt, int64_t Ns, const double* xt, const double* xs, const double* f, double* v_trg, double scale,
-                                     int mode, int cus, hipStream_t st);
+template <class R>
+hipError_t eval_laplace_fxu_centered(int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* f, R* v_trg, double scale, int mode, int cus,
+                                     hipStream_t st);
 void centered_plan(int64_t Nt, int64_t Ns, int cus, int* T, int* splits, int64_t* chunk);
 namespace {
 
@@ -129,29 +130,22 @@ KerCtx make_ctx(const KernelEntry& k, const void* ctx) {
   return c;
 }
 
-// Tile-centred fast path (centered_kernel.hpp): Laplace single layer in fp64 on problems large enough to amortise the
+// Tile-centred fast path (centered_kernel.hpp): Laplace single layer (fp64 and fp32) on problems large enough to amortise the
 // Morton sort of the targets.  SCTL_AMD_CENTERED=0 in the environment forces the exact kernel (used for A/B checks).
 bool use_centered(const KernelEntry& k, int real, int64_t Nt, int64_t Ns) {
   const char* e = std::getenv("SCTL_AMD_CENTERED");   // read per call so that a test can A/B both paths in one process
   const bool enabled = !(e && e[0] == '0');
   // Nt >= 2^18: below that the 128 targets of a wave span so much of the domain that > 10 % of the sources are "near"
   // and the exact kernel wins (measured at Nt = 2^17, Ns = 2^20: 67.8 ms vs 65.7 ms; one target per lane does not help: 66.6 ms)
-  return enabled && k.id == SCTL_AMD_LAPLACE3D_FXU && real == SCTL_AMD_F64 && Nt >= (1 << 18) && Nt < (int64_t(1) << 32) && Ns >= 65536;
+  return enabled && k.id == SCTL_AMD_LAPLACE3D_FXU && Nt >= (1 << 18) && Nt < (int64_t(1) << 32) && Ns >= 65536;
 }
 
-int eval_centered(const KernelEntry& k, int64_t Nt, int64_t Ns, const double* xt, const double* xs, const double* f, double* v, int mode,
-                  const Plan& p, hipStream_t st) {
-  HIP_TRY(eval_laplace_fxu_centered(Nt, Ns, xt, xs, f, v, k.scale, mode, cu_count(), st));
+template <class R>
+int eval_centered(const KernelEntry& k, int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* f, R* v, int mode, hipStream_t st) {
+  HIP_TRY(eval_laplace_fxu_centered<R>(Nt, Ns, xt, xs, f, v, k.scale, mode, cu_count(), st));
   g_pairs += Nt * Ns;
   g_flops += Nt * Ns * k.flops;
   return SCTL_AMD_OK;
-}
-template <class R> int eval_centered_or_fail(const KernelEntry&, int64_t, int64_t, const R*, const R*, const R*, R*, int, const Plan&, hipStream_t) {
-  return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "centred path is fp64 only");
-}
-template <> int eval_centered_or_fail<double>(const KernelEntry& k, int64_t Nt, int64_t Ns, const double* xt, const double* xs, const double* f, double* v,
-                                              int mode, const Plan& p, hipStream_t st) {
-  return eval_centered(k, Nt, Ns, xt, xs, f, v, mode, p, st);
 }
 
 template <class R>
@@ -161,7 +155,7 @@ int eval_device_t(const KernelEntry& k, int real, int64_t Nt, int64_t Ns, const 
   (void)hipGetLastError();                      // drop a stale error of an earlier, unrelated runtime call on this thread
   const Plan p = make_plan(k, real, Nt, Ns);
   const int mode = mode_for(real, digits);
-  if (use_centered(k, real, Nt, Ns)) return eval_centered_or_fail<R>(k, Nt, Ns, xt, xs, f, v, mode, p, st);
+  if (use_centered(k, real, Nt, Ns)) return eval_centered<R>(k, Nt, Ns, xt, xs, f, v, mode, st);
   EvalArgs<R> a{};
   a.Nt = Nt; a.Ns = Ns; a.xt = xt; a.xs = xs; a.xn = xn; a.f = f; a.v_trg = v; a.partial = nullptr;
   a.chunk = p.chunk; a.scale = (R)k.scale; a.ctx = make_ctx(k, ctx);
@@ -646,7 +640,7 @@ int sctl_amd_eval_plan(int kernel, int real, int64_t Nt, int64_t Ns, int digits,
     if (trg_per_lane) *trg_per_lane = T;
     if (src_splits) *src_splits = splits;
     if (workgroups) *workgroups = ((Nt + 64 * T - 1) / (64 * T)) * splits;   // one wave64 per workgroup
-    if (workspace_bytes) *workspace_bytes = (splits > 1) ? (int64_t)splits * Nt * 8 : 0;
+    if (workspace_bytes) *workspace_bytes = (splits > 1) ? (int64_t)splits * Nt * (real == SCTL_AMD_F64 ? 8 : 4) : 0;
     return SCTL_AMD_OK;
   }
   const Plan p = make_plan(*k, real, Nt, Ns);

@@ -25,9 +25,8 @@ struct AsyncBuf {
   hipError_t alloc(size_t bytes) { return hipMallocAsync(&p, bytes ? bytes : 8, st); }
 };
 
-template <int MODE> void launch_centered(const EvalArgs<double>& a, int T, dim3 grid, hipStream_t st) {
-  if (T == 1) hipLaunchKernelGGL((laplace_fxu_centered_kernel<MODE, 1>), grid, dim3(kWaveBlock), 0, st, a);
-  else hipLaunchKernelGGL((laplace_fxu_centered_kernel<MODE, 2>), grid, dim3(kWaveBlock), 0, st, a);
+template <class R, int MODE> void launch_centered(const EvalArgs<R>& a, dim3 grid, hipStream_t st) {
+  hipLaunchKernelGGL((laplace_fxu_centered_kernel<R, MODE, 2>), grid, dim3(kWaveBlock), 0, st, a);
 }
 }  // namespace
 
@@ -51,8 +50,10 @@ void centered_plan(int64_t Nt, int64_t Ns, int cus, int* T, int* splits, int64_t
   *splits = (int)((Ns + *chunk - 1) / *chunk);
 }
 
-hipError_t eval_laplace_fxu_centered(int64_t Nt, int64_t Ns, const double* xt, const double* xs, const double* f, double* v_trg, double scale,
-                                     int mode, int cus, hipStream_t st) {
+template <class R>
+hipError_t eval_laplace_fxu_centered(int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* f, R* v_trg, double scale_d, int mode, int cus,
+                                     hipStream_t st) {
+  const R scale = (R)scale_d;
   int T, splits;
   int64_t chunk;
   centered_plan(Nt, Ns, cus, &T, &splits, &chunk);
@@ -63,12 +64,12 @@ hipError_t eval_laplace_fxu_centered(int64_t Nt, int64_t Ns, const double* xt, c
   CENTERED_TRY(keys2.alloc(sizeof(uint64_t) * Nt));
   CENTERED_TRY(idx.alloc(sizeof(uint32_t) * Nt));
   CENTERED_TRY(idx2.alloc(sizeof(uint32_t) * Nt));
-  CENTERED_TRY(xts.alloc(sizeof(double) * 3 * Nt));
-  CENTERED_TRY(outs.alloc(sizeof(double) * Nt));
+  CENTERED_TRY(xts.alloc(sizeof(R) * 3 * Nt));
+  CENTERED_TRY(outs.alloc(sizeof(R) * Nt));
   const unsigned nb = (unsigned)((Nt + kBlock - 1) / kBlock);
 
-  hipLaunchKernelGGL((bbox_partial_kernel<double>), dim3(nblk_box), dim3(kBlock), 0, st, xt, Nt, (double*)part.p);
-  hipLaunchKernelGGL((morton_keys_kernel<double>), dim3(nb), dim3(kBlock), 0, st, xt, Nt, (const double*)part.p, nblk_box, (uint64_t*)keys.p,
+  hipLaunchKernelGGL((bbox_partial_kernel<R>), dim3(nblk_box), dim3(kBlock), 0, st, xt, Nt, (double*)part.p);
+  hipLaunchKernelGGL((morton_keys_kernel<R>), dim3(nb), dim3(kBlock), 0, st, xt, Nt, (const double*)part.p, nblk_box, (uint64_t*)keys.p,
                      (uint32_t*)idx.p);
   size_t tmp_bytes = 0;
   CENTERED_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (uint64_t*)keys.p, (uint64_t*)keys2.p, (uint32_t*)idx.p, (uint32_t*)idx2.p, (size_t)Nt, 0,
@@ -77,27 +78,29 @@ hipError_t eval_laplace_fxu_centered(int64_t Nt, int64_t Ns, const double* xt, c
   CENTERED_TRY(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, (uint64_t*)keys.p, (uint64_t*)keys2.p, (uint32_t*)idx.p, (uint32_t*)idx2.p, (size_t)Nt, 0, 63,
                                          st));
   const uint32_t* perm = (const uint32_t*)idx2.p;
-  hipLaunchKernelGGL((gather_points_kernel<double>), dim3(nb), dim3(kBlock), 0, st, xt, perm, Nt, (double*)xts.p);
-  CENTERED_TRY(hipMemsetAsync(outs.p, 0, sizeof(double) * Nt, st));
+  hipLaunchKernelGGL((gather_points_kernel<R>), dim3(nb), dim3(kBlock), 0, st, xt, perm, Nt, (R*)xts.p);
+  CENTERED_TRY(hipMemsetAsync(outs.p, 0, sizeof(R) * Nt, st));
 
-  EvalArgs<double> a{};
-  a.Nt = Nt; a.Ns = Ns; a.xt = (const double*)xts.p; a.xs = xs; a.xn = nullptr; a.f = f; a.v_trg = (double*)outs.p; a.partial = nullptr;
+  EvalArgs<R> a{};
+  a.Nt = Nt; a.Ns = Ns; a.xt = (const R*)xts.p; a.xs = xs; a.xn = nullptr; a.f = f; a.v_trg = (R*)outs.p; a.partial = nullptr;
   a.chunk = chunk; a.scale = scale;
   a.ctx.v[0] = kNearFactor2;
   if (const char* e = std::getenv("SCTL_AMD_EXPERIMENT_NEAR_FACTOR")) a.ctx.v[0] = std::atof(e);   // timing experiments only
   if (splits > 1) {
-    CENTERED_TRY(partial.alloc(sizeof(double) * (size_t)splits * Nt));
-    a.partial = (double*)partial.p;
+    CENTERED_TRY(partial.alloc(sizeof(R) * (size_t)splits * Nt));
+    a.partial = (R*)partial.p;
   }
   const dim3 grid((unsigned)((Nt + (int64_t)kWaveBlock * T - 1) / ((int64_t)kWaveBlock * T)), (unsigned)splits);
-  if (mode == 0) launch_centered<0>(a, T, grid, st);
-  else if (mode == 1) launch_centered<1>(a, T, grid, st);
-  else launch_centered<2>(a, T, grid, st);
+  if (mode == 0) launch_centered<R, 0>(a, grid, st);
+  else if (mode == 1) launch_centered<R, 1>(a, grid, st);
+  else launch_centered<R, (sizeof(R) == 8 ? 2 : 1)>(a, grid, st);
   CENTERED_TRY(hipGetLastError());
   if (splits > 1)
-    hipLaunchKernelGGL((reduce_splits_kernel<double>), dim3(nb), dim3(kBlock), 0, st, (double*)outs.p, (const double*)a.partial, Nt, splits, scale);
-  hipLaunchKernelGGL((scatter_add_kernel<double>), dim3(nb), dim3(kBlock), 0, st, (const double*)outs.p, perm, Nt, 1, v_trg);
+    hipLaunchKernelGGL((reduce_splits_kernel<R>), dim3(nb), dim3(kBlock), 0, st, (R*)outs.p, (const R*)a.partial, Nt, splits, scale);
+  hipLaunchKernelGGL((scatter_add_kernel<R>), dim3(nb), dim3(kBlock), 0, st, (const R*)outs.p, perm, Nt, 1, v_trg);
   return hipGetLastError();
 }
+template hipError_t eval_laplace_fxu_centered<double>(int64_t, int64_t, const double*, const double*, const double*, double*, double, int, int, hipStream_t);
+template hipError_t eval_laplace_fxu_centered<float>(int64_t, int64_t, const float*, const float*, const float*, float*, double, int, int, hipStream_t);
 
 }  // namespace sctl_amd

@@ -36,6 +36,24 @@ template <class R> __device__ __forceinline__ R wave_max(R v) {
 __device__ __forceinline__ double uniform_(double v) {
   return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
+__device__ __forceinline__ float uniform_(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ double sqrt_(double v) { return __builtin_sqrt(v); }
+__device__ __forceinline__ float sqrt_(float v) { return __builtin_sqrtf(v); }
+
+// four reals {a, b, c, d} as whole 16-byte LDS words: two double2 or one float4
+template <class R> struct Rec4;
+template <> struct Rec4<double> {
+  typedef double V __attribute__((ext_vector_type(2)));
+  static constexpr int NW = 2;
+  static __device__ __forceinline__ void put(V* p, double a, double b, double c, double d) { p[0] = V{a, b}; p[1] = V{c, d}; }
+  static __device__ __forceinline__ void get(const V* p, double (&o)[4]) { const V u = p[0], w = p[1]; o[0] = u[0]; o[1] = u[1]; o[2] = w[0]; o[3] = w[1]; }
+};
+template <> struct Rec4<float> {
+  typedef float V __attribute__((ext_vector_type(4)));
+  static constexpr int NW = 1;
+  static __device__ __forceinline__ void put(V* p, float a, float b, float c, float d) { p[0] = V{a, b, c, d}; }
+  static __device__ __forceinline__ void get(const V* p, float (&o)[4]) { const V u = p[0]; o[0] = u[0]; o[1] = u[1]; o[2] = u[2]; o[3] = u[3]; }
+};
 
 // One wave64 per workgroup: the unit that shares a centre is 64*T Morton-consecutive targets (128 for T = 2), which keeps
 // the cluster radius — and with it the fraction of near sources (3.5 % at 2^20 uniform points, vs 9 % for 512 targets) —
@@ -45,16 +63,16 @@ constexpr int kWaveBlock = 64;   // lanes per workgroup of the centred kernel
 constexpr int kWaveTile = 64;    // sources per LDS tile
 constexpr int kNearCap = 128;    // capacity of the per-wave list of pending near sources
 
-// a.xt: Morton-sorted targets; a.v_trg / a.partial: indexed like a.xt (the caller scatters back); fp64 only.
+// a.xt: Morton-sorted targets; a.v_trg / a.partial: indexed like a.xt (the caller scatters back).
 // (asking the compiler for 5-6 waves/SIMD instead of the 4 its 118 VGPRs allow costs 1-3 %: measured 464-471 vs 458 ms)
-template <int MODE, int T, int UNR = 4>
-__global__ void __launch_bounds__(kWaveBlock) laplace_fxu_centered_kernel(const EvalArgs<double> a) {
-  using R = double;
-  typedef double V __attribute__((ext_vector_type(2)));
+template <class R, int MODE, int T, int UNR = 4>
+__global__ void __launch_bounds__(kWaveBlock) laplace_fxu_centered_kernel(const EvalArgs<R> a) {
+  using V = typename Rec4<R>::V;
+  constexpr int NW = Rec4<R>::NW;
   using Ker = Laplace3D_FxU;
-  __shared__ V farB[(kWaveTile + 4) * 2];    // {x', y'}, {z', |x_s'|^2}   (+ padding records)
+  __shared__ V farB[(kWaveTile + 4) * NW];   // {x', y', z', |x_s'|^2}   (+ padding records)
   __shared__ R farF[kWaveTile + 4];          // density
-  __shared__ V nearA[(kNearCap + 2) * 2];    // {x, y}, {z, f}  original coordinates; near sources are collected over
+  __shared__ V nearA[(kNearCap + 2) * NW];   // {x, y, z, f}  original coordinates; near sources are collected over
                                              // several tiles and evaluated in batches, so the exact loop runs rarely
                                              // and with a long trip count
 
@@ -66,7 +84,7 @@ __global__ void __launch_bounds__(kWaveBlock) laplace_fxu_centered_kernel(const 
   R xt[T][3];
   R c[3];
   {
-    R lo[3] = {1.7976931348623157e308, 1.7976931348623157e308, 1.7976931348623157e308}, hi[3] = {-lo[0], -lo[0], -lo[0]};
+    R lo[3] = {max_finite<R>(), max_finite<R>(), max_finite<R>()}, hi[3] = {-lo[0], -lo[0], -lo[0]};
 #pragma unroll
     for (int j = 0; j < T; j++) {
       int64_t t = tbase + j * kWaveBlock + lane;
@@ -79,7 +97,7 @@ __global__ void __launch_bounds__(kWaveBlock) laplace_fxu_centered_kernel(const 
       }
     }
 #pragma unroll
-    for (int k = 0; k < 3; k++) c[k] = uniform_(0.5 * wave_min(lo[k]) + 0.5 * wave_max(hi[k]));
+    for (int k = 0; k < 3; k++) c[k] = uniform_(R(0.5) * wave_min(lo[k]) + R(0.5) * wave_max(hi[k]));
   }
   R m2x[T][3], tt[T], rt2 = 0;
 #pragma unroll
@@ -88,10 +106,10 @@ __global__ void __launch_bounds__(kWaveBlock) laplace_fxu_centered_kernel(const 
     tt[j] = len2(p);
     rt2 = (tt[j] > rt2) ? tt[j] : rt2;
 #pragma unroll
-    for (int k = 0; k < 3; k++) m2x[j][k] = -2.0 * p[k];
+    for (int k = 0; k < 3; k++) m2x[j][k] = R(-2) * p[k];
   }
   rt2 = uniform_(wave_max(rt2));
-  const R near_r2 = a.ctx.v[0] * rt2;   // ctx.v[0] = kNearFactor2; NaN coordinates fail every comparison => "near" => exact path
+  const R near_r2 = R(a.ctx.v[0]) * rt2;   // ctx.v[0] = kNearFactor2; NaN coordinates fail every comparison => "near" => exact path
 
   R acc[T];
 #pragma unroll
@@ -115,11 +133,11 @@ __global__ void __launch_bounds__(kWaveBlock) laplace_fxu_centered_kernel(const 
   if (ntile > 0) load_source(0);
 
   // ---- near sources: the reference-exact pair (d = x_t - x_s, masked at r = 0), evaluated in batches -----------
-  const R far_off = 1.0e3 * (1.0 + __builtin_sqrt(rt2));
+  const R far_off = R(1.0e3) * (R(1) + sqrt_(rt2));
   int nn = 0;   // pending near sources in nearA (wave-uniform)
   auto flush_near = [&]() {
     if (nn & 1) {   // pad to an even count with a null source
-      if (lane == 0) { nearA[nn * 2] = V{c[0] + far_off, c[1]}; nearA[nn * 2 + 1] = V{c[2], 0.0}; }
+      if (lane == 0) Rec4<R>::put(nearA + nn * NW, c[0] + far_off, c[1], c[2], R(0));
       __syncthreads();
     }
     R xo[T][3];   // the original target coordinates are needed only here: reloaded (L2 hit) rather than kept in 12 VGPRs
@@ -133,11 +151,12 @@ __global__ void __launch_bounds__(kWaveBlock) laplace_fxu_centered_kernel(const 
     for (int s = 0; s < nn; s += 2) {
 #pragma unroll
       for (int u = 0; u < 2; u++) {
-        const V a0 = nearA[(s + u) * 2], a1 = nearA[(s + u) * 2 + 1];
+        R q[4];
+        Rec4<R>::get(nearA + (s + u) * NW, q);
 #pragma unroll
         for (int j = 0; j < T; j++) {
-          const R d[3] = {xo[j][0] - a0[0], xo[j][1] - a0[1], xo[j][2] - a1[0]};
-          acc[j] = fma_(a1[1], rsqrt_masked<MODE, true>(len2(d), K.rsq), acc[j]);
+          const R d[3] = {xo[j][0] - q[0], xo[j][1] - q[1], xo[j][2] - q[2]};
+          acc[j] = fma_(q[3], rsqrt_masked<MODE, true>(len2(d), K.rsq), acc[j]);
         }
       }
     }
@@ -162,37 +181,41 @@ __global__ void __launch_bounds__(kWaveBlock) laplace_fxu_centered_kernel(const 
     }
     if (is_far) {
       const int q = __popcll(bf & below);
-      farB[q * 2] = V{p[0], p[1]};
-      farB[q * 2 + 1] = V{p[2], ss};
+      Rec4<R>::put(farB + q * NW, p[0], p[1], p[2], ss);
       farF[q] = f;
     } else if (is_near) {
       const int q = nn + __popcll(bn & below);
-      nearA[q * 2] = V{x[0], x[1]};
-      nearA[q * 2 + 1] = V{x[2], f};
+      Rec4<R>::put(nearA + q * NW, x[0], x[1], x[2], f);
     }
     nn += nnear;
     // pad the far list to a multiple of UNR with null sources (zero density at ~1e3 cluster radii): they contribute
     // exactly 0 and remove the low-ILP remainder loop
     if (lane < UNR - 1) {
       const int q = nfar + lane;
-      if (q < ((nfar + UNR - 1) & ~(UNR - 1))) { farB[q * 2] = V{far_off, 0.0}; farB[q * 2 + 1] = V{0.0, far_off * far_off}; farF[q] = 0.0; }
+      if (q < ((nfar + UNR - 1) & ~(UNR - 1))) { Rec4<R>::put(farB + q * NW, far_off, R(0), R(0), far_off * far_off); farF[q] = R(0); }
     }
     if (it + 1 < ntile) load_source(it + 1);
     __syncthreads();
 
     // ---- far sources: 4-instruction distance, no mask -------------------------------------------------------
+    R tacc[T];   // per-tile partial sums, folded into acc once per tile (two-level summation: matters for fp32 at Ns = 2^23)
+#pragma unroll
+    for (int j = 0; j < T; j++) tacc[j] = 0;
     for (int s = 0; s < nfar; s += UNR) {
 #pragma unroll
       for (int u = 0; u < UNR; u++) {
-        const V b0 = farB[(s + u) * 2], b1 = farB[(s + u) * 2 + 1];
+        R b[4];
+        Rec4<R>::get(farB + (s + u) * NW, b);
         const R fs = farF[s + u];
 #pragma unroll
         for (int j = 0; j < T; j++) {
-          const R r2 = fma_(m2x[j][0], b0[0], fma_(m2x[j][1], b0[1], fma_(m2x[j][2], b1[0], tt[j] + b1[1])));
-          acc[j] = fma_(fs, rsqrt_masked<MODE, false>(r2, K.rsq), acc[j]);
+          const R r2 = fma_(m2x[j][0], b[0], fma_(m2x[j][1], b[1], fma_(m2x[j][2], b[2], tt[j] + b[3])));
+          tacc[j] = fma_(fs, rsqrt_masked<MODE, false>(r2, K.rsq), tacc[j]);
         }
       }
     }
+#pragma unroll
+    for (int j = 0; j < T; j++) acc[j] += tacc[j];
   }
   __syncthreads();
   flush_near();

@@ -86,7 +86,8 @@ def test_launch_planner():
     if os.environ.get("SCTL_AMD_CENTERED") != "0":      # the headline problem takes the tile-centred Laplace path: one wave per workgroup
         head = sctl_amd.plan("Laplace3D-FxU", 0, 1 << 20, 1 << 20)
         assert head["path"] == "tile-centred" and head["src_splits"] == 16 and head["workgroups"] == 8192 * 16
-        assert sctl_amd.plan("Laplace3D-FxU", 1, 1 << 20, 1 << 20)["path"] == "exact"      # fp32 stays on the exact kernel
+        assert sctl_amd.plan("Laplace3D-FxU", 1, 1 << 20, 1 << 20)["path"] == "tile-centred"
+        assert sctl_amd.plan("Laplace3D-DxU", 0, 1 << 20, 1 << 20)["path"] == "exact"         # only the single layer has a centred form
 
 
 def test_product_tree_never_touches_the_oracle():

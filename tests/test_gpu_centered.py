@@ -72,3 +72,23 @@ def test_centred_path_accumulates_and_honours_digits(O):
     for digits, tol in ((3, 1e-2), (7, 1e-6), (12, 1e-11), (-1, 1e-13)):
         v = sctl_amd.eval_device("Laplace3D-FxU", d[0], d[1], None, d[2], digits=digits).cpu().numpy()
         assert rel_l2(v[sel], ref) <= tol, (digits, rel_l2(v[sel], ref))
+
+
+def test_centred_path_fp32(O):
+    """fp32 through the tile-centred path against the fp64 oracle (tolerance of SURVEY.md §8d) and the exact fp32 kernel."""
+    import torch
+    rng = np.random.default_rng(9)
+    n = 1 << 18
+    xt, xs, f = rng.random(n * 3).astype(np.float32), rng.random(n * 3).astype(np.float32), (rng.random(n) - 0.5).astype(np.float32)
+    assert sctl_amd.plan("Laplace3D-FxU", 1, n, n)["path"] == "tile-centred"
+    d = [torch.from_numpy(a).cuda() for a in (xt, xs, f)]
+    u = sctl_amd.eval_device("Laplace3D-FxU", d[0], d[1], None, d[2]).cpu().numpy()
+    os.environ["SCTL_AMD_CENTERED"] = "0"
+    try:
+        u_exact = sctl_amd.eval_device("Laplace3D-FxU", d[0], d[1], None, d[2]).cpu().numpy()
+    finally:
+        del os.environ["SCTL_AMD_CENTERED"]
+    sel = rng.choice(n, 300, replace=False)
+    ref = O.eval("Laplace3D-FxU", xt.reshape(n, 3)[sel].astype(np.float64).ravel().copy(), xs.astype(np.float64), None, f.astype(np.float64))
+    e_c, e_x = rel_l2(u[sel], ref), rel_l2(u_exact[sel], ref)
+    assert e_c <= 1e-4 and e_c <= 3 * e_x + 1e-6, (e_c, e_x)
