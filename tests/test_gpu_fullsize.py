@@ -21,6 +21,7 @@ def _cloud(seed, Nt, Ns, info, dt=np.float64):
     ("Stokes3D-FxU", 1 << 18, np.float64, 1e-12),       # config 3
     ("Helmholtz3D-FxU", 1 << 17, np.float64, 1e-12),    # config 5 functor
     ("Laplace3D-FxU", 1 << 21, np.float32, 1e-4),       # config 4 precision (tolerance vs the f64 oracle)
+    ("Laplace3D-FxU", 1 << 23, np.float32, 1e-4),       # config 4 at its full size (2^23 x 2^23; ~11 s on one GPU)
 ])
 def test_full_size_target_subset_against_oracle(O, name, N, dt, tol):
     import torch
