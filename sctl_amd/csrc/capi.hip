@@ -86,15 +86,18 @@ struct Plan {
   int64_t workspace_bytes;
 };
 
-// Geometry: enough workgroups for >= 4 per CU; prefer 2 targets per lane (halves LDS reads per pair)
-// once there are enough targets, otherwise split the source range (SURVEY.md §8e sizes: 2^14 .. 2^23).
+// Geometry: targets per lane from the target count, then split the source range until there are enough workgroups
+// (SURVEY.md §8e sizes: 2^14 .. 2^23).
 Plan make_plan(const KernelEntry& k, int real, int64_t Nt, int64_t Ns) {
   // workgroups wanted: 8 per CU (32 waves) — measured +4 % over 4 per CU at Nt = 2^17, Ns = 2^20 and on the Stokeslet at
   // 2^18 — except for tiny problems, which are launch-bound and lose time to the extra partial sums
   const int64_t want = (int64_t)cu_count() * ((double)Nt * (double)Ns < 2147483648.0 ? 4 : 8);
   Plan p{};
-  int t = (k.k1 * (real == SCTL_AMD_F64 ? 2 : 1) > 8) ? 1 : 2;   // big accumulator sets (Stokes3D-FxT fp64): 1 target per lane
-  if ((Nt + kBlock * t - 1) / (kBlock * t) < want) t = 1;
+  // Two targets per lane halve the LDS reads per pair and double the independent chains: 5-7 % faster than one target
+  // per lane from Nt = 2^16 up on every kernel (Stokeslet 2^18: 56.2 vs 59.7 ms; traction kernel 72.5 vs 77.9 ms), with
+  // the source range split further to keep the chip full; at Nt <= 2^14 one target per lane wins (0.18 vs 0.20 ms).
+  (void)k;
+  const int t = (Nt >= 32768) ? 2 : 1;
   p.t_idx = (t == 1) ? 0 : 1;
   p.wg_x = (Nt + (int64_t)kBlock * t - 1) / ((int64_t)kBlock * t);
   if (p.wg_x < 1) p.wg_x = 1;

@@ -1,0 +1,51 @@
+"""Randomised parity sweep: random kernel, precision, sizes (including values around every internal boundary), digits and
+entry point (host buffers / device tensors / operator handle), always against the CPU oracle on the same inputs."""
+import numpy as np
+import pytest
+
+import sctl_amd
+from conftest import ctx_for, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+BOUNDARY = [1, 2, 63, 64, 65, 127, 128, 255, 256, 257, 511, 512, 513, 1023, 1025, 2047, 4097]
+
+
+def _size(rng):
+    return int(rng.choice(BOUNDARY)) if rng.random() < 0.5 else int(rng.integers(1, 6000))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_cases_against_oracle(O, seed):
+    import torch
+    rng = np.random.default_rng(1000 + seed)
+    for _ in range(12):
+        name = sctl_amd.KERNEL_NAMES[int(rng.integers(0, len(sctl_amd.KERNEL_NAMES)))]
+        info = sctl_amd.kernel_info(name)
+        dt = np.float64 if rng.random() < 0.6 else np.float32
+        Nt, Ns = _size(rng), _size(rng)
+        digits = int(rng.choice([-1, -1, 16, 12, 9, 5])) if dt == np.float64 else -1
+        scale = float(rng.choice([1.0, 1e-3, 1e3]))
+        xt = (scale * rng.random(Nt * 3)).astype(dt)
+        xs = (scale * rng.random(Ns * 3)).astype(dt)
+        xn = (rng.random(Ns * info["nd"]) - 0.5).astype(dt)
+        f = (rng.random(Ns * info["k0"]) - 0.5).astype(dt)
+        ctx = ctx_for(name)
+        if ctx is not None:
+            ctx = ctx / scale                      # keep k r of order 10
+        ref = O.eval(name, xt.astype(np.float64), xs.astype(np.float64), xn.astype(np.float64), f.astype(np.float64), ctx=ctx)
+        how = int(rng.integers(0, 3))
+        if how == 0:
+            u = sctl_amd.eval_host(name, xt, xs, xn, f, digits=digits, ctx=ctx)
+        elif how == 1:
+            d = [torch.from_numpy(a).cuda() for a in (xt, xs, xn, f)]
+            u = sctl_amd.eval_device(name, *d, digits=digits, ctx=ctx).cpu().numpy()
+        else:
+            op = sctl_amd.DirectOp(name, dt, ctx=ctx)
+            op.set_targets(xt)
+            op.set_sources(xs, xn)
+            u = op.eval(f, digits=digits)
+            op.close()
+        tol = (1e-12 if digits < 0 or digits >= 15 else 10.0 * 10.0 ** (-digits)) if dt == np.float64 else 3e-5
+        err = rel_l2(u, ref)
+        assert np.all(np.isfinite(u)) and err <= tol, (name, dt, Nt, Ns, digits, how, err)
