@@ -132,17 +132,13 @@ def main():
     def step(timed):
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            out_slab.zero_()
             e0.record()
-            op.local_eval(r_trg[t0 * 3:t1 * 3], r_src, n_src, v_src, out_slab)
+            op.eval_slab(r_trg, r_src, n_src, v_src, out_slab)        # this rank's targets x all sources (HIP kernels)
             e1.record()
             kern_ms.append((e0, e1))
         else:
-            out_slab.zero_()
-            op.local_eval(r_trg[t0 * 3:t1 * 3], r_src, n_src, v_src, out_slab)
-        if world > 1:
-            dist.all_gather_into_tensor(out, out_slab)
-        return out if world > 1 else out_slab
+            op.eval_slab(r_trg, r_src, n_src, v_src, out_slab)
+        return op.gather(r_trg, out_slab, out) if world > 1 else out_slab   # one all-gather, back to the caller's order
 
     def fence():
         torch.cuda.synchronize()
@@ -171,7 +167,7 @@ def main():
     local_pairs = float(t1 - t0) * float(N)              # pairs ONE launch (this rank) processes
     achieved = local_pairs * fpp / (k_ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[dtype]
-    plan = sctl_amd.plan(kernel, 0 if dtype == "f64" else 1, t1 - t0, N, args.digits)
+    plan = sctl_amd.plan(kernel, 0 if dtype == "f64" else 1, t1 - t0, N, args.digits, nt_whole=N)
 
     if rank == 0:
         line = {
@@ -180,7 +176,7 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": dtype, "data": "synthetic",
             "config": {"workload": desc, "kernel": kernel, "n_trg": N, "n_src": N, "digits": args.digits,
-                       "partition": "targets block-partitioned over %d GPU(s), sources replicated, %s" %
+                       "partition": "targets block-partitioned (Morton order) over %d GPU(s), sources replicated, %s" %
                                     (world, "one RCCL all-gather of the potential slabs per step" if world > 1 else "no collective"),
                        "launch": plan},
             "roofline": {"bound": "fp64_valu" if dtype == "f64" else "fp32_valu", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",

@@ -87,6 +87,15 @@ int sctl_amd_flops_per_pair(int kernel);
 int sctl_amd_eval_device(int kernel, int real, int64_t Nt, int64_t Ns, const void* r_trg, const void* r_src, const void* n_src,
                          const void* v_src, void* v_trg, int digits, const void* ctx, int ctx_bytes, void* stream);
 
+/* The same for a SPATIALLY COMPACT slab of a larger target set: the Nt targets are a contiguous run of the Nt_whole
+ * targets in space-filling-curve order, as a rank of a multi-GPU job holds them (fmm-wrapper.txx:504-512 partitions the
+ * targets; here the partition follows a Morton curve so that a slab keeps the point density of the whole set).  The
+ * result is the same as sctl_amd_eval_device's; Nt_whole only informs the choice between the exact kernel and the
+ * tile-centred one, which depends on the target density and not on the count.  Nt_whole >= Nt. */
+int sctl_amd_eval_device_slab(int kernel, int real, int64_t Nt, int64_t Ns, int64_t Nt_whole, const void* r_trg, const void* r_src,
+                              const void* n_src, const void* v_src, void* v_trg, int digits, const void* ctx, int ctx_bytes,
+                              void* stream);
+
 /* Host-buffer form: the drop-in for GenericKernel<uKer>::Eval<Real,enable_openmp,digits>
  * (generic-kernel.hpp:123) and for the type-erased static entry ParticleFMM stores
  * (generic-kernel.hpp:110, fmm-wrapper.txx:152-153).  All arrays are HOST pointers; the call uploads,
@@ -130,15 +139,16 @@ void sctl_amd_counters(int64_t* pair_interactions, int64_t* sctl_flops);
 void sctl_amd_reset_counters(void);
 
 /* Launch geometry chosen for a problem (for benchmarks and DESIGN.md; no side effects):
- * targets per lane, source splits, workgroups, and bytes of the partial-sum workspace. */
-int sctl_amd_eval_plan(int kernel, int real, int64_t Nt, int64_t Ns, int digits, int* trg_per_lane, int* src_splits,
-                       int64_t* workgroups, int64_t* workspace_bytes);
+ * targets per lane, source splits, workgroups, and bytes of the partial-sum workspace.
+ * Nt_whole: as in sctl_amd_eval_device_slab; 0 (or Nt) for a whole target set. */
+int sctl_amd_eval_plan(int kernel, int real, int64_t Nt, int64_t Ns, int64_t Nt_whole, int digits, int* trg_per_lane,
+                       int* src_splits, int64_t* workgroups, int64_t* workspace_bytes);
 
 /* Which device algorithm sctl_amd_eval_device/_host will use for a problem: 0 = the exact all-pairs kernel
  * (d = x_t - x_s per pair, as generic-kernel.txx:83), 1 = the tile-centred Laplace path (targets Morton-sorted on the
  * device, far sources through r2 = |x_t'|^2 + |x_s'|^2 - 2 x_t'.x_s', near sources exact).
  * Negative = error code.  Setting SCTL_AMD_CENTERED=0 in the environment forces 0. */
-int sctl_amd_eval_path(int kernel, int real, int64_t Nt, int64_t Ns);
+int sctl_amd_eval_path(int kernel, int real, int64_t Nt, int64_t Ns, int64_t Nt_whole);
 
 #ifdef __cplusplus
 }

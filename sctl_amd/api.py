@@ -21,7 +21,7 @@ KERNEL_NAMES = ["Laplace3D-FxU", "Laplace3D-DxU", "Laplace3D-FxdU", "Stokes3D-Fx
 
 # every symbol include/sctl_amd.h declares (tests/test_boundary.py checks the header against this list and the .so)
 SYMBOLS = ["sctl_amd_version", "sctl_amd_last_error", "sctl_amd_device_count", "sctl_amd_kernel_id", "sctl_amd_kernel_name",
-           "sctl_amd_kernel_info", "sctl_amd_flops_per_pair", "sctl_amd_eval_device", "sctl_amd_eval_host", "sctl_amd_eval_host_multi",
+           "sctl_amd_kernel_info", "sctl_amd_flops_per_pair", "sctl_amd_eval_device", "sctl_amd_eval_device_slab", "sctl_amd_eval_host", "sctl_amd_eval_host_multi",
            "sctl_amd_kernel_matrix_device", "sctl_amd_kernel_matrix_host", "sctl_amd_counters", "sctl_amd_reset_counters",
            "sctl_amd_eval_plan", "sctl_amd_eval_path", "sctl_amd_op_create", "sctl_amd_op_set_targets",
            "sctl_amd_op_set_sources", "sctl_amd_op_eval", "sctl_amd_op_destroy"]
@@ -52,6 +52,7 @@ def lib():
     L.sctl_amd_kernel_id.argtypes = [C.c_char_p]
     L.sctl_amd_kernel_info.argtypes = [ci] + [C.POINTER(C.c_int)] * 4 + [C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.sctl_amd_eval_device.argtypes = [ci, ci, i64, i64, vp, vp, vp, vp, vp, ci, vp, ci, vp]
+    L.sctl_amd_eval_device_slab.argtypes = [ci, ci, i64, i64, i64, vp, vp, vp, vp, vp, ci, vp, ci, vp]
     L.sctl_amd_eval_host.argtypes = [ci, ci, i64, i64, vp, vp, vp, vp, vp, ci, vp, ci, ci]
     L.sctl_amd_eval_host_multi.argtypes = [ci, ci, i64, i64, vp, vp, vp, vp, vp, ci, vp, ci, C.POINTER(C.c_int), ci]
     L.sctl_amd_kernel_matrix_device.argtypes = [ci, ci, i64, i64, vp, vp, vp, vp, ci, vp, ci, vp]
@@ -59,8 +60,8 @@ def lib():
     L.sctl_amd_counters.argtypes = [C.POINTER(i64), C.POINTER(i64)]
     L.sctl_amd_counters.restype = None
     L.sctl_amd_reset_counters.restype = None
-    L.sctl_amd_eval_plan.argtypes = [ci, ci, i64, i64, ci, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(i64), C.POINTER(i64)]
-    L.sctl_amd_eval_path.argtypes = [ci, ci, i64, i64]
+    L.sctl_amd_eval_plan.argtypes = [ci, ci, i64, i64, i64, ci, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(i64), C.POINTER(i64)]
+    L.sctl_amd_eval_path.argtypes = [ci, ci, i64, i64, i64]
     L.sctl_amd_op_create.argtypes = [ci, ci, C.POINTER(C.c_int), ci, C.POINTER(vp)]
     L.sctl_amd_op_set_targets.argtypes = [vp, i64, vp]
     L.sctl_amd_op_set_sources.argtypes = [vp, i64, vp, vp]
@@ -105,11 +106,11 @@ def flops_per_pair(name):
     return lib().sctl_amd_flops_per_pair(kernel_id(name))
 
 
-def plan(name, real, Nt, Ns, digits=-1):
+def plan(name, real, Nt, Ns, digits=-1, nt_whole=0):
     t, s = C.c_int(), C.c_int()
     wg, ws = C.c_int64(), C.c_int64()
-    _check(lib().sctl_amd_eval_plan(kernel_id(name), real, Nt, Ns, digits, C.byref(t), C.byref(s), C.byref(wg), C.byref(ws)), "eval_plan")
-    path = lib().sctl_amd_eval_path(kernel_id(name), real, Nt, Ns)
+    _check(lib().sctl_amd_eval_plan(kernel_id(name), real, Nt, Ns, nt_whole, digits, C.byref(t), C.byref(s), C.byref(wg), C.byref(ws)), "eval_plan")
+    path = lib().sctl_amd_eval_path(kernel_id(name), real, Nt, Ns, nt_whole)
     return dict(trg_per_lane=t.value, src_splits=s.value, workgroups=wg.value, workspace_bytes=ws.value,
                 path="tile-centred" if path == 1 else "exact")
 
@@ -181,8 +182,9 @@ def _t_ptr(t, torch_dtype, n, what):
     return C.c_void_p(t.data_ptr())
 
 
-def eval_device(name, r_trg, r_src, n_src, v_src, v_trg=None, digits=-1, ctx=None, stream=None):
-    """GenericKernel::Eval on torch CUDA tensors, enqueued on `stream` (default: torch's current stream)."""
+def eval_device(name, r_trg, r_src, n_src, v_src, v_trg=None, digits=-1, ctx=None, stream=None, nt_whole=None):
+    """GenericKernel::Eval on torch CUDA tensors, enqueued on `stream` (default: torch's current stream).
+    nt_whole: the targets are a spatially compact slab of a set of that many (sctl_amd_eval_device_slab)."""
     import torch
     info = kernel_info(name)
     tdt = r_trg.dtype
@@ -193,10 +195,10 @@ def eval_device(name, r_trg, r_src, n_src, v_src, v_trg=None, digits=-1, ctx=Non
     keep, cp, cb = _ctx_blob(info, ctx)
     with torch.cuda.device(r_trg.device):
         st = stream if stream is not None else torch.cuda.current_stream()
-        _check(lib().sctl_amd_eval_device(info["id"], real, Nt, Ns, _t_ptr(r_trg, tdt, Nt * 3, "r_trg"), _t_ptr(r_src, tdt, Ns * 3, "r_src"),
-                                          _t_ptr(n_src, tdt, Ns * info["nd"], "n_src"), _t_ptr(v_src, tdt, Ns * info["k0"], "v_src"),
-                                          _t_ptr(v_trg, tdt, Nt * info["k1"], "v_trg"), digits, cp, cb, C.c_void_p(st.cuda_stream)),
-               "eval_device")
+        _check(lib().sctl_amd_eval_device_slab(info["id"], real, Nt, Ns, Nt if nt_whole is None else nt_whole, _t_ptr(r_trg, tdt, Nt * 3, "r_trg"),
+                                               _t_ptr(r_src, tdt, Ns * 3, "r_src"), _t_ptr(n_src, tdt, Ns * info["nd"], "n_src"),
+                                               _t_ptr(v_src, tdt, Ns * info["k0"], "v_src"), _t_ptr(v_trg, tdt, Nt * info["k1"], "v_trg"), digits, cp, cb,
+                                               C.c_void_p(st.cuda_stream)), "eval_device")
     return v_trg
 
 

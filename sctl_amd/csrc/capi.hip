@@ -135,12 +135,17 @@ KerCtx make_ctx(const KernelEntry& k, const void* ctx) {
 
 // Tile-centred fast path (centered_kernel.hpp): Laplace single layer (fp64 and fp32) on problems large enough to amortise the
 // Morton sort of the targets.  SCTL_AMD_CENTERED=0 in the environment forces the exact kernel (used for A/B checks).
-bool use_centered(const KernelEntry& k, int real, int64_t Nt, int64_t Ns) {
+// nt_whole: size of the target set the Nt targets were cut from as a spatially compact slab (= Nt for a whole set).
+bool use_centered(const KernelEntry& k, int real, int64_t Nt, int64_t Ns, int64_t nt_whole = 0) {
   const char* e = std::getenv("SCTL_AMD_CENTERED");   // read per call so that a test can A/B both paths in one process
-  const bool enabled = !(e && e[0] == '0');
-  // Nt >= 2^18: below that the 128 targets of a wave span so much of the domain that > 10 % of the sources are "near"
-  // and the exact kernel wins (measured at Nt = 2^17, Ns = 2^20: 67.8 ms vs 65.7 ms; one target per lane does not help: 66.6 ms)
-  return enabled && k.id == SCTL_AMD_LAPLACE3D_FXU && Nt >= (1 << 18) && Nt < (int64_t(1) << 32) && Ns >= 65536;
+  const bool enabled = !(e && e[0] == '0'), forced = (e && e[0] == '1');
+  if (!enabled || k.id != SCTL_AMD_LAPLACE3D_FXU || Nt >= (int64_t(1) << 32)) return false;
+  if (forced) return Nt >= 128 && Ns >= 64;
+  // What decides is the target DENSITY: with fewer than 2^18 targets in the domain the 128 targets of a wave span so much
+  // of it that > 10 % of the sources are "near" and the exact kernel wins (measured at Nt = 2^17, Ns = 2^20: 67.8 ms vs
+  // 65.7 ms; one target per lane does not help: 66.6 ms).  A compact slab of 2^17 out of 2^20 has the density of the
+  // whole set and gains like it (59.4 ms against 64.7 ms exact, tools/slab_locality.py).
+  return (Nt > nt_whole ? Nt : nt_whole) >= (1 << 18) && Nt >= (1 << 17) && Ns >= 65536;
 }
 
 template <class R>
@@ -153,12 +158,12 @@ int eval_centered(const KernelEntry& k, int64_t Nt, int64_t Ns, const R* xt, con
 
 template <class R>
 int eval_device_t(const KernelEntry& k, int real, int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* xn, const R* f, R* v, int digits,
-                  const void* ctx, hipStream_t st) {
+                  const void* ctx, hipStream_t st, int64_t nt_whole = 0) {
   if (Nt == 0 || Ns == 0) return SCTL_AMD_OK;   // nothing to add (generic-kernel.txx:153-186 degenerates to v_trg += 0)
   (void)hipGetLastError();                      // drop a stale error of an earlier, unrelated runtime call on this thread
   const Plan p = make_plan(k, real, Nt, Ns);
   const int mode = mode_for(real, digits);
-  if (use_centered(k, real, Nt, Ns)) return eval_centered<R>(k, Nt, Ns, xt, xs, f, v, mode, st);
+  if (use_centered(k, real, Nt, Ns, nt_whole)) return eval_centered<R>(k, Nt, Ns, xt, xs, f, v, mode, st);
   EvalArgs<R> a{};
   a.Nt = Nt; a.Ns = Ns; a.xt = xt; a.xs = xs; a.xn = xn; a.f = f; a.v_trg = v; a.partial = nullptr;
   a.chunk = p.chunk; a.scale = (R)k.scale; a.ctx = make_ctx(k, ctx);
@@ -412,18 +417,29 @@ int sctl_amd_flops_per_pair(int kernel) {
   return k ? 3 + k->flops + 2 * k->k0 * k->k1 : SCTL_AMD_ERR_UNKNOWN_KERNEL;
 }
 
-int sctl_amd_eval_device(int kernel, int real, int64_t Nt, int64_t Ns, const void* r_trg, const void* r_src, const void* n_src,
-                         const void* v_src, void* v_trg, int digits, const void* ctx, int ctx_bytes, void* stream) {
+static int eval_device_entry(int kernel, int real, int64_t Nt, int64_t Ns, int64_t nt_whole, const void* r_trg, const void* r_src, const void* n_src,
+                             const void* v_src, void* v_trg, int digits, const void* ctx, int ctx_bytes, void* stream) {
   const KernelEntry* k = registry(kernel);
   int rc = check_common(k, real, Nt, Ns, r_trg, r_src, n_src, ctx_bytes, ctx);
   if (rc) return rc;
   if ((Ns > 0 && !v_src) || (Nt > 0 && !v_trg)) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "null density or potential array");
+  if (nt_whole < Nt) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "a slab cannot hold more targets than the set it was cut from");
   if (device_count_quiet() <= 0) return fail(SCTL_AMD_ERR_NO_DEVICE, "no HIP device: libsctl_amd has no CPU fallback");
   if (real == SCTL_AMD_F64)
     return eval_device_t<double>(*k, real, Nt, Ns, (const double*)r_trg, (const double*)r_src, (const double*)n_src, (const double*)v_src,
-                                 (double*)v_trg, digits, ctx, (hipStream_t)stream);
+                                 (double*)v_trg, digits, ctx, (hipStream_t)stream, nt_whole);
   return eval_device_t<float>(*k, real, Nt, Ns, (const float*)r_trg, (const float*)r_src, (const float*)n_src, (const float*)v_src, (float*)v_trg,
-                              digits, ctx, (hipStream_t)stream);
+                              digits, ctx, (hipStream_t)stream, nt_whole);
+}
+
+int sctl_amd_eval_device(int kernel, int real, int64_t Nt, int64_t Ns, const void* r_trg, const void* r_src, const void* n_src,
+                         const void* v_src, void* v_trg, int digits, const void* ctx, int ctx_bytes, void* stream) {
+  return eval_device_entry(kernel, real, Nt, Ns, Nt, r_trg, r_src, n_src, v_src, v_trg, digits, ctx, ctx_bytes, stream);
+}
+
+int sctl_amd_eval_device_slab(int kernel, int real, int64_t Nt, int64_t Ns, int64_t Nt_whole, const void* r_trg, const void* r_src,
+                              const void* n_src, const void* v_src, void* v_trg, int digits, const void* ctx, int ctx_bytes, void* stream) {
+  return eval_device_entry(kernel, real, Nt, Ns, Nt_whole, r_trg, r_src, n_src, v_src, v_trg, digits, ctx, ctx_bytes, stream);
 }
 
 int sctl_amd_eval_host_multi(int kernel, int real, int64_t Nt, int64_t Ns, const void* r_trg, const void* r_src, const void* n_src,
@@ -629,14 +645,14 @@ void sctl_amd_counters(int64_t* pair_interactions, int64_t* sctl_flops) {
 }
 void sctl_amd_reset_counters(void) { g_pairs = 0; g_flops = 0; }
 
-int sctl_amd_eval_plan(int kernel, int real, int64_t Nt, int64_t Ns, int digits, int* trg_per_lane, int* src_splits, int64_t* workgroups,
-                       int64_t* workspace_bytes) {
+int sctl_amd_eval_plan(int kernel, int real, int64_t Nt, int64_t Ns, int64_t Nt_whole, int digits, int* trg_per_lane, int* src_splits,
+                       int64_t* workgroups, int64_t* workspace_bytes) {
   (void)digits;
   const KernelEntry* k = registry(kernel);
   if (!k) return fail(SCTL_AMD_ERR_UNKNOWN_KERNEL, "unknown kernel id");
   if (real != SCTL_AMD_F64 && real != SCTL_AMD_F32) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "real must be SCTL_AMD_F64 or SCTL_AMD_F32");
   if (Nt < 0 || Ns < 0) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "negative size");
-  if (use_centered(*k, real, Nt, Ns)) {
+  if (use_centered(*k, real, Nt, Ns, Nt_whole)) {
     int T, splits;
     int64_t chunk;
     centered_plan(Nt, Ns, cu_count(), &T, &splits, &chunk);
@@ -654,11 +670,11 @@ int sctl_amd_eval_plan(int kernel, int real, int64_t Nt, int64_t Ns, int digits,
   return SCTL_AMD_OK;
 }
 
-int sctl_amd_eval_path(int kernel, int real, int64_t Nt, int64_t Ns) {
+int sctl_amd_eval_path(int kernel, int real, int64_t Nt, int64_t Ns, int64_t Nt_whole) {
   const KernelEntry* k = registry(kernel);
   if (!k) return fail(SCTL_AMD_ERR_UNKNOWN_KERNEL, "unknown kernel id");
   if (real != SCTL_AMD_F64 && real != SCTL_AMD_F32) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "real must be SCTL_AMD_F64 or SCTL_AMD_F32");
-  return use_centered(*k, real, Nt, Ns) ? 1 : 0;
+  return use_centered(*k, real, Nt, Ns, Nt_whole) ? 1 : 0;
 }
 
 }  // extern "C"

@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, Nt, Ns, name, out_dir):
+def _worker(rank, world, port, Nt, Ns, name, out_dir, compact=True):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -39,21 +39,25 @@ def _worker(rank, world, port, Nt, Ns, name, out_dir):
         v_out += torch.from_numpy(v)
         return v_out
 
-    op = ShardedDirectSum(name, local_eval=oracle_eval)
+    op = ShardedDirectSum(name, local_eval=oracle_eval, compact=compact)
     t = [torch.from_numpy(a) for a in (xt, xs, xn, f)]
     u = op.eval(*t)
     u2 = op.eval(*t, out=u)                        # EvalDirect overwrites: a second call gives the same answer
     ref = O.eval(name, xt, xs, xn, f, nthreads=2)
     t0, t1 = slab_bounds(Nt, rank, world)
+    idx = op.slab_indices(t[0]).numpy()               # which targets this rank evaluated: a compact box, or an index range
+    box = (xt.reshape(-1, 3)[idx].max(0) - xt.reshape(-1, 3)[idx].min(0)).prod()
     ok = (np.linalg.norm(u.numpy() - ref) <= 1e-14 * np.linalg.norm(ref)) and torch.equal(u, u2) and (t1 - t0) in (Nt // world, Nt // world + 1)
+    ok = ok and idx.size == t1 - t0 and ((box < 0.75 or world != 2) if compact else np.array_equal(idx, np.arange(t0, t1)))
     with open(os.path.join(out_dir, "rank%d" % rank), "w") as fh:
         fh.write("ok" if ok else "bad")
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,Nt", [(2, 1000), (2, 1001), (3, 1000)])
-def test_sharded_direct_sum_gloo(tmp_path, world, Nt):
-    mp.spawn(_worker, args=(world, _free_port(), Nt, 300, "Stokes3D-DxU", str(tmp_path)), nprocs=world, join=True)
+@pytest.mark.parametrize("world,Nt,compact", [(2, 1000, True), (2, 1001, True), (3, 1000, True), (2, 1001, False)])
+def test_sharded_direct_sum_gloo(tmp_path, world, Nt, compact):
+    """Slabs cut from the Morton order (default) or by index: the same potential in the caller's order either way."""
+    mp.spawn(_worker, args=(world, _free_port(), Nt, 300, "Stokes3D-DxU", str(tmp_path), compact), nprocs=world, join=True)
     for r in range(world):
         assert open(os.path.join(str(tmp_path), "rank%d" % r)).read() == "ok"
 
@@ -64,3 +68,56 @@ def test_slab_bounds_cover_all_targets():
         for G in (1, 2, 3, 8):
             b = [slab_bounds(Nt, g, G) for g in range(G)]
             assert b[0][0] == 0 and b[-1][1] == Nt and all(b[i][1] == b[i + 1][0] for i in range(G - 1))
+
+
+def _ring_worker(rank, world, port, name, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from sctl_amd.distributed import RingDirectSum
+    O = oracle.restatement()
+    info = O.info(name)
+    rng = np.random.default_rng(8)
+    nts = [211, 0, 57][:world] if world == 3 else [300, 123]        # unequal blocks, one rank without targets
+    nss = [150, 333, 1][:world] if world == 3 else [200, 77]
+    xt_all = [rng.random(n * 3) for n in nts]
+    xs_all = [rng.random(n * 3) for n in nss]
+    xn_all = [rng.random(n * info["nd"]) - 0.5 for n in nss]
+    f_all = [rng.random(n * info["k0"]) - 0.5 for n in nss]
+
+    def oracle_eval(r_trg, r_src, n_src, v_src, v_out):
+        v = O.eval(name, r_trg.numpy().copy(), r_src.numpy().copy(), n_src.numpy().copy(), v_src.numpy().copy(), nthreads=2)
+        v_out += torch.from_numpy(v)
+        return v_out
+
+    op = RingDirectSum(name, local_eval=oracle_eval)
+    u = op.eval(*[torch.from_numpy(a[rank]) for a in (xt_all, xs_all, xn_all, f_all)])
+    ref = O.eval(name, xt_all[rank], np.concatenate(xs_all), np.concatenate(xn_all), np.concatenate(f_all), nthreads=2) if nts[rank] else np.zeros(0)
+    ok = u.numel() == nts[rank] * info["k1"] and (nts[rank] == 0 or np.linalg.norm(u.numpy() - ref) <= 1e-13 * np.linalg.norm(ref))
+    with open(os.path.join(out_dir, "ring%d" % rank), "w") as fh:
+        fh.write("ok" if ok else "bad")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ring_direct_sum_gloo(tmp_path, world):
+    """Partitioned inputs, sources rotating around the ring (the reference's MPI EvalDirect, fmm-wrapper.txx:537-558)."""
+    mp.spawn(_ring_worker, args=(world, _free_port(), "Laplace3D-DxU", str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert open(os.path.join(str(tmp_path), "ring%d" % r)).read() == "ok"
+
+
+def test_morton_order_is_a_permutation_and_local():
+    from sctl_amd.distributed import morton_order
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(3 * 4096, dtype=torch.float64, generator=g) * 5 - 2          # any box, not just the unit cube
+    p = morton_order(x)
+    assert torch.equal(torch.sort(p).values, torch.arange(4096))
+    assert torch.equal(p, morton_order(x.clone()))                                # a pure function of the coordinates
+    xs = x.view(-1, 3)[p]
+    hop = lambda pts: (pts[1:] - pts[:-1]).norm(dim=1).mean()                     # neighbours on the curve are neighbours in space
+    assert hop(xs) < 0.2 * hop(x.view(-1, 3))
+    assert morton_order(torch.zeros(0, dtype=torch.float64)).numel() == 0
+    same = torch.ones(3 * 10, dtype=torch.float32)                               # degenerate box: stable order
+    assert torch.equal(morton_order(same), torch.arange(10))

@@ -92,3 +92,29 @@ def test_centred_path_fp32(O):
     ref = O.eval("Laplace3D-FxU", xt.reshape(n, 3)[sel].astype(np.float64).ravel().copy(), xs.astype(np.float64), None, f.astype(np.float64))
     e_c, e_x = rel_l2(u[sel], ref), rel_l2(u_exact[sel], ref)
     assert e_c <= 1e-4 and e_c <= 3 * e_x + 1e-6, (e_c, e_x)
+
+
+def test_compact_slab_uses_the_centred_path_and_matches(O):
+    """A rank's share of a multi-GPU job (sctl_amd_eval_device_slab): 2^17 targets cut from the Morton order of 2^20, all
+    the sources.  Same potential as the exact kernel and the oracle; the slab hint only changes the path taken; and the
+    one-process-per-GPU driver (world size 1 here) returns the caller's order."""
+    import torch
+    from sctl_amd.distributed import morton_order
+    rng = np.random.default_rng(77)
+    n_whole, G, ns = 1 << 20, 8, 1 << 17
+    xt_all = torch.from_numpy(rng.random(n_whole * 3)).cuda()
+    xs, f = torch.from_numpy(rng.random(ns * 3)).cuda(), torch.from_numpy(rng.random(ns) - 0.5).cuda()
+    perm = morton_order(xt_all)
+    n = n_whole // G
+    assert sctl_amd.plan("Laplace3D-FxU", 0, n, ns)["path"] == "exact"
+    assert sctl_amd.plan("Laplace3D-FxU", 0, n, ns, nt_whole=n_whole)["path"] == "tile-centred"
+    for g in (0, 3, 7):
+        slab = xt_all.view(-1, 3)[perm[g * n:(g + 1) * n]].contiguous().view(-1)
+        u = sctl_amd.eval_device("Laplace3D-FxU", slab, xs, None, f, nt_whole=n_whole).cpu().numpy()
+        u_exact = sctl_amd.eval_device("Laplace3D-FxU", slab, xs, None, f).cpu().numpy()
+        assert rel_l2(u, u_exact) <= 2e-14, (g, rel_l2(u, u_exact))
+        sel = rng.choice(n, 200, replace=False)
+        ref = O.eval("Laplace3D-FxU", slab.cpu().numpy().reshape(n, 3)[sel].ravel().copy(), xs.cpu().numpy(), None, f.cpu().numpy())
+        assert rel_l2(u[sel], ref) <= 1e-12
+    with pytest.raises(sctl_amd.api.SctlAmdError):
+        sctl_amd.eval_device("Laplace3D-FxU", slab, xs, None, f, nt_whole=n - 1)         # a slab larger than its whole
