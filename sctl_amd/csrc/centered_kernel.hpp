@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(kWaveBlock) laplace_fxu_centered_kernel(const 
 
   const int lane = threadIdx.x;
   const int64_t tbase = (int64_t)blockIdx.x * (kWaveBlock * T);
-  const typename Ker::template Consts<R> K;
+  const typename Ker::template Consts<R> K(nullptr);
 
   // ---- targets of this lane, cluster centre (bounding-box midpoint) and radius --------------------------------
   R xt[T][3];

@@ -40,7 +40,16 @@ template <> struct VecOf<double> { typedef double type __attribute__((ext_vector
 template <> struct VecOf<float> { typedef float type __attribute__((ext_vector_type(4))); static constexpr int N = 4; };
 
 // sources per unrolled loop body: 4-8 independent accumulation chains in flight per lane
+#ifdef SCTL_AMD_EXP_UNROLL   // timing experiments only (tools/)
+template <int T, int K1> struct UnrollOf { static constexpr int value = SCTL_AMD_EXP_UNROLL; };
+#else
 template <int T, int K1> struct UnrollOf { static constexpr int value = (T * K1 >= 8) ? 1 : ((T * K1 >= 3) ? 2 : 4); };
+#endif
+#ifdef SCTL_AMD_EXP_WAVES
+#define SCTL_AMD_EVAL_ATTR __attribute__((amdgpu_waves_per_eu(SCTL_AMD_EXP_WAVES, SCTL_AMD_EXP_WAVES)))
+#else
+#define SCTL_AMD_EVAL_ATTR
+#endif
 
 template <class R> __device__ __forceinline__ R max_finite();
 template <> __device__ __forceinline__ double max_finite<double>() { return 1.7976931348623157e308; }
@@ -49,7 +58,7 @@ __device__ __forceinline__ double fabs_(double x) { return __builtin_fabs(x); }
 __device__ __forceinline__ float fabs_(float x) { return __builtin_fabsf(x); }
 
 template <class Ker, class R, int MODE, int T>
-__global__ void __launch_bounds__(kBlock) eval_kernel(const EvalArgs<R> a) {
+__global__ void __launch_bounds__(kBlock) SCTL_AMD_EVAL_ATTR eval_kernel(const EvalArgs<R> a) {
   constexpr int K0 = Ker::K0, K1 = Ker::K1, ND = Ker::ND, NREC = Ker::NREC;
   using V = typename VecOf<R>::type;
   constexpr int VN = VecOf<R>::N;
@@ -59,7 +68,9 @@ __global__ void __launch_bounds__(kBlock) eval_kernel(const EvalArgs<R> a) {
 
   const int tid = threadIdx.x;
   const int64_t tbase = (int64_t)blockIdx.x * (kBlock * T);
-  const typename Ker::template Consts<R> K;
+  using KC = typename Ker::template Consts<R>;
+  __shared__ double kscratch[KC::LDS_DOUBLES > 0 ? KC::LDS_DOUBLES : 1];
+  const KC K(kscratch);
 
   R xt[T][3], acc[T][K1];
 #pragma unroll
@@ -109,8 +120,10 @@ __global__ void __launch_bounds__(kBlock) eval_kernel(const EvalArgs<R> a) {
     // A wave that had to repair more than 1/8 of its tiles (e.g. targets == sources in shuffled order at small N)
     // stops speculating and runs masked from then on.
     R tacc[T][K1];
-    auto run_tile = [&](auto masked_tag) {
+    auto run_tile_v = [&](auto masked_tag, auto variant_tag) {
       constexpr bool MASKED = decltype(masked_tag)::value;
+      constexpr bool VARIANT = decltype(variant_tag)::value;
+      K.begin_tile();
 #pragma unroll
       for (int j = 0; j < T; j++)
 #pragma unroll
@@ -128,7 +141,8 @@ __global__ void __launch_bounds__(kBlock) eval_kernel(const EvalArgs<R> a) {
 #pragma unroll
         for (int j = 0; j < T; j++) {
           const R d[3] = {xt[j][0] - rec[0], xt[j][1] - rec[1], xt[j][2] - rec[2]};
-          Ker::template pair<R, MODE, MASKED>(tacc[j], d, rec, a.ctx, K);
+          if constexpr (KC::HAS_VARIANT) Ker::template pair<R, MODE, MASKED, VARIANT>(tacc[j], d, rec, a.ctx, K);
+          else Ker::template pair<R, MODE, MASKED>(tacc[j], d, rec, a.ctx, K);
         }
       };
       if (ns == kTile) {   // every tile but possibly the last: constant trip count, unrolled
@@ -138,10 +152,19 @@ __global__ void __launch_bounds__(kBlock) eval_kernel(const EvalArgs<R> a) {
         for (int s = 0; s < ns; s++) one_source(s);
       }
     };
+    // a kernel with a launch-uniform special case (Helmholtz: real wavenumber) gets its own straight-line copy of the loop
+    auto run_tile = [&](auto masked_tag) {
+      if constexpr (KC::HAS_VARIANT) {
+        if (K.variant(a.ctx)) run_tile_v(masked_tag, std::true_type());
+        else run_tile_v(masked_tag, std::false_type());
+      } else {
+        run_tile_v(masked_tag, std::false_type());
+      }
+    };
     bool repaired = true;
     if (!always_masked) {
       run_tile(std::false_type());
-      bool bad = false;
+      bool bad = K.tile_bad(a.ctx);
 #pragma unroll
       for (int j = 0; j < T; j++)
 #pragma unroll
@@ -190,8 +213,10 @@ template <class Ker, class R, int MODE>
 __global__ void __launch_bounds__(kBlock) matrix_kernel(int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* xn, R* M, R scale, KerCtx ctx) {
   constexpr int K0 = Ker::K0, K1 = Ker::K1, ND = Ker::ND, NREC = Ker::NREC;
   const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  using KC = typename Ker::template Consts<R>;
+  __shared__ double kscratch[KC::LDS_DOUBLES > 0 ? KC::LDS_DOUBLES : 1];
+  const KC K(kscratch);        // before the early return: the constructor may synchronise the workgroup
   if (t >= Nt) return;
-  const typename Ker::template Consts<R> K;
   for (int64_t s = blockIdx.y; s < Ns; s += gridDim.y) {   // gridDim.y is capped at 65535
   R x[3], n[3] = {0, 0, 0}, d[3];
 #pragma unroll

@@ -107,5 +107,104 @@ SCTL_AMD_HD double exp_fast(double x, const Coeffs& K) {
   return (x != x) ? x : e;                  // NaN in -> NaN out
 }
 
+// ---- table-driven forms (what the device kernel's inner loop runs) ------------------------------------------------------
+// A workgroup fills two small LDS tables once, with the polynomial code above, and every pair then needs only a short
+// polynomial in the distance to the nearest table node:
+//   sincos: nodes j pi/256, j = 0..511 (one full period: no quadrant logic), x = n pi/256 + y, |y| <= pi/512;
+//           sin x = S_j + (S_j (cos y - 1) + C_j sin y), cos x = C_j + (C_j (cos y - 1) - S_j sin y), with
+//           sin y = y + y z (s1 + s2 z), cos y - 1 = z (c1 + c2 z), z = y^2 (truncation < 8e-17).  Two-piece reduction
+//           (33-bit head, exact product for |n| < 2^20, i.e. |x| < 1.2e4): the ABSOLUTE error stays ~1e-16, which is what a
+//           kernel value cos + i sin of unit modulus needs; larger arguments take the libm path in the caller.
+//   exp:    nodes 2^(j/64), x = n ln2/64 + r, |r| <= ln2/128, e^r - 1 by a degree-5 polynomial (truncation 3.5e-17 rel).
+// 16 + 15 fp64 issue slots against 28 + 24 for the table-free code.
+constexpr int kTrigNodes = 512, kExpNodes = 64;
+constexpr int kTableDoubles = 2 * kTrigNodes + kExpNodes;   // [sin_j, cos_j] pairs, then 2^(j/64)
+constexpr double kSincosTabMaxArg = 1.2e4;
+
+struct TabCoeffs {
+  double inv_h, h1, h2, s1, s2, c1, c2, inv_e, e1, e2, p2, p3, p4;
+  SCTL_AMD_HD TabCoeffs() {
+    inv_h = 8.14873308630504119e+01;                      // 256/pi
+    h1 = -1.57079632673412561417e+00 / 128;               // -(pi/256), first 33 bits (fdlibm's pio2_1, scaled exactly)
+    h2 = -6.07710050650619224932e-11 / 128;               // -(pi/256 - head)
+    s1 = -1.66666666666666666667e-01; s2 = 8.33333333333333333333e-03;
+    c1 = -0.5; c2 = 4.16666666666666666667e-02;
+    inv_e = 64 * 1.44269504088896338700e+00;              // 64 log2(e)
+    e1 = -6.93147180369123816490e-01 / 64;                // -(ln2/64), head with 32 significant bits
+    e2 = -1.90821492927058770002e-10 / 64;
+    p2 = 1.66666666666666666667e-01; p3 = 4.16666666666666666667e-02; p4 = 8.33333333333333333333e-03;   // 1/3!, 1/4!, 1/5!
+  }
+#ifdef __HIPCC__
+  __device__ __forceinline__ void pin() {
+    asm volatile("" : "+s"(inv_h)); asm volatile("" : "+s"(h1)); asm volatile("" : "+s"(h2)); asm volatile("" : "+s"(s1)); asm volatile("" : "+s"(s2));
+    asm volatile("" : "+s"(c2)); asm volatile("" : "+s"(inv_e)); asm volatile("" : "+s"(e1)); asm volatile("" : "+s"(e2));
+    asm volatile("" : "+s"(p2)); asm volatile("" : "+s"(p3)); asm volatile("" : "+s"(p4));
+  }
+#endif
+};
+
+// Table entries, each from an argument reduced EXACTLY in integers (no rounding of j pi/256 beyond one multiplication
+// of a number <= pi/4): node j = quadrant q, offset m/128 of a quadrant, folded to |angle| <= pi/4.
+SCTL_AMD_HD void trig_node(int j, double& s, double& c, const Coeffs& K) {
+  int q = (j >> 7) & 3, m = j & 127;
+  if (m > 64) { m -= 128; q = (q + 1) & 3; }
+  double sk, ck;
+  sincos_kernel(m * (3.14159265358979323846 / 256), sk, ck, K);
+  const double s0 = (q & 1) ? ck : sk, c0 = (q & 1) ? sk : ck;
+  s = (q & 2) ? -s0 : s0;
+  c = ((q + 1) & 2) ? -c0 : c0;
+}
+SCTL_AMD_HD double exp2_node(int j, const Coeffs& K) { return j == 0 ? 1.0 : exp_fast(j * (6.93147180559945309417e-01 / 64), K); }
+
+// fill table[kTableDoubles] cooperatively: lane `tid` of `nthreads`
+SCTL_AMD_HD void fill_tables(double* table, int tid, int nthreads, const Coeffs& K) {
+  for (int j = tid; j < kTrigNodes; j += nthreads) trig_node(j, table[2 * j], table[2 * j + 1], K);
+  for (int j = tid; j < kExpNodes; j += nthreads) table[2 * kTrigNodes + j] = exp2_node(j, K);
+}
+
+// Round-to-nearest-integer by the magic-number addition: t = a b + 1.5 2^52 has unit ulp, so t - magic is rint(a b) and the
+// low dword of t holds that integer in two's complement (|a b| < 2^31) -- one fma + one add instead of mul + rint + cvt.
+constexpr double kRoundMagic = 6755399441055744.0;
+SCTL_AMD_HD int low_dword(double t) {
+  long long b;
+  __builtin_memcpy(&b, &t, 8);
+  return (int)(unsigned)(unsigned long long)b;
+}
+
+// precondition: |x| <= kSincosTabMaxArg
+SCTL_AMD_HD void sincos_tab(double x, double& s, double& c, const TabCoeffs& K, const double* table) {
+  const double t = fma_(x, K.inv_h, kRoundMagic);
+  const double n = t - kRoundMagic;
+  double y = fma_(n, K.h1, x);
+  y = fma_(n, K.h2, y);
+  const int j = low_dword(t) & (kTrigNodes - 1);
+  const double sj = table[2 * j], cj = table[2 * j + 1];
+  const double z = y * y;
+  const double sy = fma_(y * z, fma_(z, K.s2, K.s1), y);
+  const double cm1 = z * fma_(z, K.c2, K.c1);
+  s = fma_(sj, cm1, fma_(cj, sy, sj));
+  c = fma_(cj, cm1, fma_(-sj, sy, cj));
+}
+
+// x must lie in [-800, 800] (the caller clamps: beyond that the result is 0 or inf anyway); NaN in -> NaN out
+SCTL_AMD_HD double exp_tab_clamped(double xc, const TabCoeffs& K, const double* table) {
+  const double tm = fma_(xc, K.inv_e, kRoundMagic);
+  const double n = tm - kRoundMagic;
+  double r = fma_(n, K.e1, xc);
+  r = fma_(n, K.e2, r);
+  const int ni = low_dword(tm);
+  const double t = table[2 * kTrigNodes + (ni & (kExpNodes - 1))];
+  double p = fma_(K.p4, r, K.p3);
+  p = fma_(p, r, K.p2);
+  p = fma_(p, r, 0.5);
+  const double em1 = fma_(r * r, p, r);
+  return __builtin_ldexp(fma_(t, em1, t), ni >> 6);
+}
+
+SCTL_AMD_HD double exp_tab(double x, const TabCoeffs& K, const double* table) {
+  const double e = exp_tab_clamped(__builtin_fmin(__builtin_fmax(x, -800.0), 800.0), K, table);
+  return (x != x) ? x : e;                  // fmin/fmax drop a NaN: restore it
+}
+
 }  // namespace fastmath
 }  // namespace sctl_amd

@@ -79,11 +79,47 @@ template <int MODE, bool MASKED> __device__ __forceinline__ float rsqrt_masked(f
 }
 
 // Per-kernel constants, constructed once at kernel entry and passed to every pair() call.
-template <class R> struct DefaultConsts { RsqConst<R> rsq; };
-template <class R> struct HelmholtzConsts {
+// A kernel may ask for LDS_DOUBLES doubles of workgroup scratch, which its Consts constructor fills (all lanes of the
+// workgroup call it; it may synchronise).
+template <class R> struct DefaultConsts {
+  static constexpr int LDS_DOUBLES = 0;
+  static constexpr bool HAS_VARIANT = false;   // true: pair<R, MODE, MASKED, VARIANT> exists and variant(ctx) picks it per launch
   RsqConst<R> rsq;
-  fastmath::Coeffs fm;
-  __device__ __forceinline__ HelmholtzConsts() { fm.pin(); }
+  __device__ __forceinline__ explicit DefaultConsts(double*) {}
+  // hooks of the speculative (unmasked) tile pass of eval_kernel: a kernel whose fast path has a precondition records
+  // violations per lane and reports them at the end of the tile, which is then re-run on the careful path
+  __device__ __forceinline__ void begin_tile() const {}
+  __device__ __forceinline__ bool tile_bad(const KerCtx&) const { return false; }
+};
+template <class R> struct HelmholtzConsts;
+template <> struct HelmholtzConsts<float> {          // fp32: libm sincosf / expf
+  static constexpr int LDS_DOUBLES = 0;
+  static constexpr bool HAS_VARIANT = true;
+  __device__ __forceinline__ bool variant(const KerCtx& ctx) const { return ctx.v[1] == 0; }
+  RsqConst<float> rsq;
+  __device__ __forceinline__ explicit HelmholtzConsts(double*) {}
+  __device__ __forceinline__ void begin_tile() const {}
+  __device__ __forceinline__ bool tile_bad(const KerCtx&) const { return false; }
+};
+template <> struct HelmholtzConsts<double> {         // fp64: table-driven sincos / exp (fastmath.hpp), tables in LDS
+  static constexpr int LDS_DOUBLES = fastmath::kTableDoubles;
+  static constexpr bool HAS_VARIANT = true;            // VARIANT = real wavenumber: no exponential
+  __device__ __forceinline__ bool variant(const KerCtx& ctx) const { return ctx.v[1] == 0; }
+  RsqConst<double> rsq;
+  fastmath::TabCoeffs tc;
+  const double* table;
+  __device__ __forceinline__ explicit HelmholtzConsts(double* lds) : table(lds) {
+    {
+      const fastmath::Coeffs full;                   // the table-free polynomials, used here only
+      fastmath::fill_tables(lds, (int)threadIdx.x, (int)blockDim.x, full);
+    }
+    __syncthreads();
+    tc.pin();
+  }
+  // the table-driven sincos needs |Re k| r <= kSincosTabMaxArg: the speculative pass only tracks the largest distance
+  mutable double rmax = 0;
+  __device__ __forceinline__ void begin_tile() const { rmax = 0; }
+  __device__ __forceinline__ bool tile_bad(const KerCtx& ctx) const { return !(__builtin_fabs(ctx.v[0]) * rmax <= fastmath::kSincosTabMaxArg); }
 };
 
 template <class R> __device__ __forceinline__ R fma_(R a, R b, R c);
@@ -260,29 +296,40 @@ struct Helmholtz3D_FxU {
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0]; rec[4] = f[1]; rec[5] = 0;
   }
-  template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx& ctx, const Consts<R>& K) {
+  template <class R, int MODE, bool MASKED, bool REAL_K = false> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx& ctx, const Consts<R>& K) {
     const R r2 = len2(d);
     const R rinv = rsqrt_masked<MODE, MASKED>(r2, K.rsq);
     const R r = r2 * rinv;
     R sn, cs;
-    sincos_(R(ctx.v[0]) * r, sn, cs, K.fm);
-    const R amp = exp_(-R(ctx.v[1]) * r, K.fm) * rinv;
+    sincos_<MASKED>(R(ctx.v[0]) * r, r, sn, cs, K);
+    R amp = rinv;
+    if (!REAL_K) amp *= exp_(r, ctx, K);
     const R gr = amp * cs, gi = amp * sn;
     acc[0] = fma_(gr, rec[3], fma_(-gi, rec[4], acc[0]));
     acc[1] = fma_(gi, rec[3], fma_(gr, rec[4], acc[1]));
   }
-  // fp64: straight-line Cody-Waite + polynomial code (fastmath.hpp); arguments beyond 1.6e6 take the libm path
-  static __device__ __forceinline__ void sincos_(double x, double& s, double& c, const fastmath::Coeffs& fm) {
-#ifdef SCTL_AMD_EXPERIMENT_NO_LIBM_FALLBACK   // experiment switch only (tools/): wrong beyond |x| = 1.6e6
-    fastmath::sincos_reduced(x, s, c, fm);
-#else
-    if (__builtin_expect(__builtin_fabs(x) > fastmath::kSincosMaxArg, 0)) ::sincos(x, &s, &c);
-    else fastmath::sincos_reduced(x, s, c, fm);
-#endif
+  // fp64: Cody-Waite reduction to the nearest node of an LDS table + a short polynomial (fastmath.hpp).  Arguments beyond
+  // 1.2e4 (two thousand wavelengths) need libm: the speculative pass (MASKED = false) runs the table path unconditionally,
+  // as straight-line code, and only records the largest distance (one v_max_f64) for the end-of-tile check; the careful pass
+  // branches per pair.
+  template <bool MASKED> static __device__ __forceinline__ void sincos_(double x, double r, double& s, double& c, const HelmholtzConsts<double>& K) {
+    if (!MASKED) {
+      K.rmax = __builtin_fmax(K.rmax, r);
+      fastmath::sincos_tab(x, s, c, K.tc, K.table);
+    } else if (__builtin_expect(__builtin_fabs(x) > fastmath::kSincosTabMaxArg, 0)) {
+      ::sincos(x, &s, &c);
+    } else {
+      fastmath::sincos_tab(x, s, c, K.tc, K.table);
+    }
   }
-  static __device__ __forceinline__ void sincos_(float x, float& s, float& c, const fastmath::Coeffs&) { ::sincosf(x, &s, &c); }
-  static __device__ __forceinline__ double exp_(double x, const fastmath::Coeffs& fm) { return fastmath::exp_fast(x, fm); }
-  static __device__ __forceinline__ float exp_(float x, const fastmath::Coeffs&) { return ::expf(x); }
+  template <bool MASKED> static __device__ __forceinline__ void sincos_(float x, float, float& s, float& c, const HelmholtzConsts<float>&) { ::sincosf(x, &s, &c); }
+  // exp(-Im k r): r >= 0 is clamped to 800/|Im k| (one v_min_f64; a NaN distance turns into the cap, but then rinv is NaN
+  // too and the product stays NaN), so the argument handed to the table code is within its +-800 range
+  static __device__ __forceinline__ double exp_(double r, const KerCtx& ctx, const HelmholtzConsts<double>& K) {
+    const double rc = __builtin_fmin(r, 800.0 / __builtin_fabs(ctx.v[1]));
+    return fastmath::exp_tab_clamped(-ctx.v[1] * rc, K.tc, K.table);
+  }
+  static __device__ __forceinline__ float exp_(float r, const KerCtx& ctx, const HelmholtzConsts<float>&) { return ::expf(-float(ctx.v[1]) * r); }
 };
 
 }  // namespace sctl_amd

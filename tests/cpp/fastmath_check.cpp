@@ -10,9 +10,12 @@ int main() {
   using namespace sctl_amd::fastmath;
   const Coeffs K;
   srand48(1);
-  double es = 0, ec = 0, ee = 0;
+  const TabCoeffs T;
+  static double table[kTableDoubles];
+  for (int t = 0; t < 7; t++) fill_tables(table, t, 7, K);      // any cooperative split fills every entry
+  double es = 0, ec = 0, ee = 0, ts = 0, tc = 0, te = 0;
   for (int i = 0; i < 4000000; i++) {
-    const double scale = (i % 4 == 0) ? 1.0 : (i % 4 == 1) ? 30.0 : (i % 4 == 2) ? 3000.0 : 1.5e6;
+    const double scale = (i % 5 == 0) ? 1.0 : (i % 5 == 1) ? 30.0 : (i % 5 == 2) ? 3000.0 : (i % 5 == 3) ? 1.2e4 : 1.5e6;
     const double x = (drand48() * 2 - 1) * scale;
     double s, c;
     sincos_reduced(x, s, c, K);
@@ -22,7 +25,18 @@ int main() {
     const double t = (drand48() * 2 - 1) * ((i % 2) ? 5.0 : 700.0);
     const long double el = expl((long double)t);
     ee = fmax(ee, fabs((double)((exp_fast(t, K) - el) / el)));
+    te = fmax(te, fabs((double)((exp_tab(t, T, table) - el) / el)));
+    if (fabs(x) <= kSincosTabMaxArg) {
+      sincos_tab(x, s, c, T, table);
+      ts = fmax(ts, fabs((double)(s - sl)));
+      tc = fmax(tc, fabs((double)(c - cl)));
+    }
   }
+  double s1, c1;
+  sincos_tab(0.0, s1, c1, T, table);
+  const bool tab_specials = exp_tab(-1e9, T, table) == 0.0 && std::isinf(exp_tab(1e9, T, table)) && exp_tab(0.0, T, table) == 1.0 &&
+                            exp_tab(NAN, T, table) != exp_tab(NAN, T, table) && s1 == 0.0 && c1 == 1.0;
+  printf("tab_abs_err_sin %.3e\ntab_abs_err_cos %.3e\ntab_rel_err_exp %.3e\ntab_specials %d\n", ts, tc, te, (int)tab_specials);
   // specials
   const double z = exp_fast(-1e9, K), big = exp_fast(1e9, K), one = exp_fast(0.0, K), nn = exp_fast(NAN, K);
   double s0, c0;

@@ -14,3 +14,6 @@ def test_fastmath_against_libm(tmp_path):
     assert v["max_abs_err_sin"] < 4e-16 and v["max_abs_err_cos"] < 4e-16      # |x| up to 1.5e6
     assert v["max_rel_err_exp"] < 4e-16                                        # |x| up to 700
     assert v["specials"] == 1                                                  # exp(-huge)=0, exp(huge)=inf, exp(0)=1, NaN, sincos(0)
+    # the table-driven forms the device loop runs (tables filled by the polynomial code, as a workgroup does)
+    assert v["tab_abs_err_sin"] < 4e-16 and v["tab_abs_err_cos"] < 4e-16      # |x| up to 1.2e4
+    assert v["tab_rel_err_exp"] < 4e-16 and v["tab_specials"] == 1

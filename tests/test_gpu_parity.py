@@ -246,3 +246,24 @@ def test_reused_host_buffers_are_always_re_read(O):
         assert rel_l2(op.eval(fbuf), ref[(ub, uf)]) < 1e-12, it
         assert rel_l2(sctl_amd.eval_host(name, xt, buf, na, fbuf), ref[(ub, uf)]) < 1e-12, it
     op.close()
+
+
+@pytest.mark.parametrize("k", [(7.5, 0.0), (40.0, 0.3), (3.0, 60.0), (5.0, -2.0), (3.0e4, 0.0), (2.0e4, 1.0), (0.0, 4.0), (-12.0, 0.5)],
+                         ids=lambda k: "k=%g%+gi" % k)
+@pytest.mark.parametrize("shape", [(700, 900), (5000, 6000)], ids=lambda s: "%dx%d" % s)
+def test_helmholtz_wavenumbers(O, k, shape):
+    """The fp64 Helmholtz kernel's table-driven sincos / exp over the wavenumber plane: real k (no exponential), strong
+    decay and growth, and |Re k| r beyond the table path's range (the tile is re-run through libm).  The small shape runs
+    the careful (masked) pass only, the large one the speculative pass; sources include the targets (r = 0 pairs)."""
+    nt, ns = shape
+    rng = np.random.default_rng(31)
+    xs = rng.random(ns * 3)
+    xt = np.concatenate([xs[:3 * 40], rng.random((nt - 40) * 3)])
+    f = rng.random(ns * 2) - 0.5
+    ctx = np.array(k, dtype=np.float64)
+    ref = O.eval("Helmholtz3D-FxU", xt, xs, None, f, ctx=ctx)
+    u = sctl_amd.eval_host("Helmholtz3D-FxU", xt, xs, None, f, ctx=ctx)
+    assert np.all(np.isfinite(u))
+    # |Re k| r of 1e4 amplifies the rounding of r itself (relative 1e-16) to an absolute phase error of 1e-12
+    tol = 1e-12 if abs(k[0]) < 1e3 else 1e-10
+    assert rel_l2(u, ref) <= tol, rel_l2(u, ref)
