@@ -133,10 +133,38 @@ int sctl_amd_op_set_sources(sctl_amd_op* op, int64_t Ns, const void* r_src, cons
 int sctl_amd_op_eval(sctl_amd_op* op, const void* v_src, void* v_trg, int accumulate, int digits, const void* ctx, int ctx_bytes);
 void sctl_amd_op_destroy(sctl_amd_op* op);
 
+/* ---- BoundaryIntegralOp near field: ComputeNearInterac (boundary_integral.txx:1079-1142) -------------------------- */
+/* The step that follows the far field in ComputePotential (:608-614): for every element the precomputed operator block
+ * K_near_ ((elem_nds_cnt[e]*src_dim) x (near_elem_cnt[e]*trg_dim), row-major) is applied to the element's density,
+ * U_ = F_ . K_near_ (:1092-1102); the results are permuted by near_scatter_index (ScatterForward, :1129: out[i] =
+ * in[index[i]]) and each target adds its near_trg_cnt[i] entries starting at near_trg_dsp[i] (:1131-1140).
+ * create() takes exactly the HOST arrays BoundaryIntegralOp::SetupNear leaves behind (:816-1012) and keeps them on the
+ * device; K_near is the concatenation of the blocks in element order (the reference's K_near with K_near_dsp, :854-857).
+ * K_near_cnt may be NULL (every block present); K_near_cnt[e] == 0 marks an element without a matrix (MatrixFree, :849),
+ * whose near targets receive nothing from this routine.  trg_dim is the number of potential components per target
+ * (KDIM1, or KDIM1/3 when the operator was set up with trg_normal_dot_prod, :1080).
+ * apply: F holds sum(elem_nds_cnt)*src_dim densities in element order; U (Ntrg*trg_dim) is ACCUMULATED into.
+ * A handle may be used from one thread at a time. */
+typedef struct sctl_amd_near sctl_amd_near;
+int sctl_amd_near_create(int real, int device, int64_t Nelem, int src_dim, int trg_dim, const int64_t* elem_nds_cnt,
+                         const int64_t* near_elem_cnt, const int64_t* K_near_cnt, const void* K_near, int64_t Ntrg,
+                         const int64_t* near_scatter_index, const int64_t* near_trg_cnt, const int64_t* near_trg_dsp,
+                         sctl_amd_near** op);
+int sctl_amd_near_apply_host(sctl_amd_near* op, const void* F, void* U);                   /* HOST arrays            */
+int sctl_amd_near_apply_device(sctl_amd_near* op, const void* F, void* U, void* stream);   /* DEVICE arrays, enqueue */
+/* Sizes of an operator: density and potential lengths, near-list entries, bytes of K_near resident in HBM (the
+ * algorithmic traffic of one application), workgroups of the GEMV launch.  Any output pointer may be NULL. */
+int sctl_amd_near_info(const sctl_amd_near* op, int64_t* density_len, int64_t* potential_len, int64_t* near_entries,
+                       int64_t* operator_bytes, int64_t* workgroups);
+void sctl_amd_near_destroy(sctl_amd_near* op);
+
 /* ---- accounting (the reference's Profile::IncrementCounter(FLOP, Ns*Nt*FLOPS()), generic-kernel.txx:188) ---- */
 /* Process-wide counters, updated atomically by every eval / kernel_matrix call. */
 void sctl_amd_counters(int64_t* pair_interactions, int64_t* sctl_flops);
 void sctl_amd_reset_counters(void);
+/* Frees the device scratch memory the library keeps per (device, stream) between calls (partial sums, the sort buffers
+ * of the tile-centred path: up to ~0.3 GB per stream at 2^20 points).  Waits for the devices.  Optional. */
+void sctl_amd_trim(void);
 
 /* Launch geometry chosen for a problem (for benchmarks and DESIGN.md; no side effects):
  * targets per lane, source splits, workgroups, and bytes of the partial-sum workspace.

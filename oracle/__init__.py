@@ -204,3 +204,66 @@ def rel_l2(a, b):
     b = np.asarray(b, dtype=np.float64).ravel()
     n = np.linalg.norm(b)
     return float(np.linalg.norm(a - b) / n) if n > 0 else float(np.linalg.norm(a - b))
+
+
+# ---- BoundaryIntegralOp near field (boundary_integral.txx:784-1012 setup, :1079-1142 apply) ---------------------------------
+NEAR_INT_ARRAYS = ("elem_nds_cnt", "near_elem_cnt", "K_near_cnt", "near_scatter_index", "near_trg_cnt", "near_trg_dsp")
+
+
+def reference_near(name, xt, xn_trg, xs, xn, wts, f, trg_normal_dot_prod=False, tol=1e-10, nodes_per_elem=4, upsample=1, rad=0.1):
+    """The REAL reference's BoundaryIntegralOp on the synthetic PatchElemList of oracle/ref_near_shim.cpp (build container only).
+    Returns u_total (ComputePotential), u_near (ComputeNearInterac alone) and the near-operator arrays SetupNear built."""
+    path = os.path.join(_HERE, "_ref", "libsctl_ref_near.so")
+    lib = C.CDLL(path)
+    Ns = xs.size // 3
+    Nt = 0 if xt is None else xt.size // 3
+    NT = Nt if Nt else Ns
+    nelem = (Ns + nodes_per_elem - 1) // nodes_per_elem
+    near_cap, k_cap = NT * nelem, NT * nelem * nodes_per_elem * 9
+    out = dict(u_total=np.zeros(NT * 9), u_near=np.zeros(NT * 9), K_near=np.zeros(k_cap))
+    for k, n in (("elem_nds_cnt", nelem), ("near_elem_cnt", nelem), ("K_near_cnt", nelem), ("near_scatter_index", near_cap), ("near_trg_cnt", NT), ("near_trg_dsp", NT)):
+        out[k] = np.zeros(n, dtype=np.int64)
+    sizes = np.zeros(8, dtype=np.int64)
+    fn = lib.sctl_ref_boundary_near
+    fn.argtypes = ([C.c_char_p, C.c_int64, C.c_int64] + [C.c_void_p] * 6 + [C.c_int, C.c_double, C.c_int, C.c_int, C.c_double] + [C.c_void_p] * 2 + [C.c_int64] +
+                   [C.c_void_p] * 4 + [C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64])
+    rc = fn(name.encode(), Nt, Ns, _ptr(xt), _ptr(xn_trg), _ptr(xs), _ptr(xn), _ptr(wts), _ptr(f), 1 if trg_normal_dot_prod else 0, tol, nodes_per_elem,
+            upsample, rad, _ptr(out["u_total"]), _ptr(out["u_near"]), out["u_total"].size, _ptr(sizes), _ptr(out["elem_nds_cnt"]),
+            _ptr(out["near_elem_cnt"]), _ptr(out["K_near_cnt"]), nelem, _ptr(out["near_scatter_index"]), near_cap, _ptr(out["near_trg_cnt"]),
+            _ptr(out["near_trg_dsp"]), NT, _ptr(out["K_near"]), k_cap)
+    assert rc == 0, rc
+    ntrg, ne, nnear, klen, ulen = (int(v) for v in sizes[:5])
+    assert ntrg == NT and ne == nelem
+    out["u_total"], out["u_near"], out["K_near"] = out["u_total"][:ulen].copy(), out["u_near"][:ulen].copy(), out["K_near"][:klen].copy()
+    out["near_scatter_index"] = out["near_scatter_index"][:nnear].copy()
+    return out
+
+
+def near_apply_restatement(k0, k1, elem_nds_cnt, near_elem_cnt, K_near_cnt, K_near, near_scatter_index, near_trg_cnt, near_trg_dsp, F, U=None):
+    """CPU restatement of BoundaryIntegralOp::ComputeNearInterac (boundary_integral.txx:1079-1142) for precomputed operator
+    matrices: per element U_ = F_ . K_near_ (:1092-1102), permutation by near_scatter_index (:1129, ScatterForward:
+    out[i] = in[index[i]]), per target the sum of its near_trg_cnt entries in order (:1131-1140), ACCUMULATED into U.
+    k1 is the number of potential components per target (already divided by 3 under trg_normal_dot_prod)."""
+    nelem, ntrg = elem_nds_cnt.size, near_trg_cnt.size
+    nds_dsp = np.concatenate([[0], np.cumsum(elem_nds_cnt)])
+    near_dsp = np.concatenate([[0], np.cumsum(near_elem_cnt)])
+    k_dsp = np.concatenate([[0], np.cumsum(K_near_cnt)])
+    u_near = np.zeros(int(near_dsp[-1]) * k1, dtype=K_near.dtype)
+    for e in range(nelem):
+        sd, td = int(elem_nds_cnt[e]) * k0, int(near_elem_cnt[e]) * k1
+        if sd == 0 or td == 0 or K_near_cnt[e] == 0:
+            continue
+        Kb = K_near[int(k_dsp[e]) * k0 * k1:int(k_dsp[e]) * k0 * k1 + sd * td].reshape(sd, td)
+        Fe = F[int(nds_dsp[e]) * k0:int(nds_dsp[e]) * k0 + sd]
+        acc = np.zeros(td, dtype=K_near.dtype)
+        for s in range(sd):                     # row by row, the order of a row-major GEMV
+            acc += Fe[s] * Kb[s]
+        u_near[int(near_dsp[e]) * k1:int(near_dsp[e]) * k1 + td] = acc
+    u_sc = u_near.reshape(-1, k1)[near_scatter_index]
+    if U is None:
+        U = np.zeros(ntrg * k1, dtype=K_near.dtype)
+    Uv = U.reshape(ntrg, k1)
+    for i in range(ntrg):
+        for p in range(int(near_trg_dsp[i]), int(near_trg_dsp[i]) + int(near_trg_cnt[i])):
+            Uv[i] += u_sc[p]
+    return U

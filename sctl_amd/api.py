@@ -22,9 +22,10 @@ KERNEL_NAMES = ["Laplace3D-FxU", "Laplace3D-DxU", "Laplace3D-FxdU", "Stokes3D-Fx
 # every symbol include/sctl_amd.h declares (tests/test_boundary.py checks the header against this list and the .so)
 SYMBOLS = ["sctl_amd_version", "sctl_amd_last_error", "sctl_amd_device_count", "sctl_amd_kernel_id", "sctl_amd_kernel_name",
            "sctl_amd_kernel_info", "sctl_amd_flops_per_pair", "sctl_amd_eval_device", "sctl_amd_eval_device_slab", "sctl_amd_eval_host", "sctl_amd_eval_host_multi",
-           "sctl_amd_kernel_matrix_device", "sctl_amd_kernel_matrix_host", "sctl_amd_counters", "sctl_amd_reset_counters",
+           "sctl_amd_kernel_matrix_device", "sctl_amd_kernel_matrix_host", "sctl_amd_counters", "sctl_amd_reset_counters", "sctl_amd_trim",
            "sctl_amd_eval_plan", "sctl_amd_eval_path", "sctl_amd_op_create", "sctl_amd_op_set_targets",
-           "sctl_amd_op_set_sources", "sctl_amd_op_eval", "sctl_amd_op_destroy"]
+           "sctl_amd_op_set_sources", "sctl_amd_op_eval", "sctl_amd_op_destroy", "sctl_amd_near_create", "sctl_amd_near_apply_host",
+           "sctl_amd_near_apply_device", "sctl_amd_near_info", "sctl_amd_near_destroy"]
 
 
 class SctlAmdError(RuntimeError):
@@ -36,6 +37,26 @@ def library_path():
     return os.environ.get("SCTL_AMD_LIB") or os.path.join(_HERE, "libsctl_amd.so")
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64.so (soname libamdhip64.so.7, found through its
+    RPATH); libsctl_amd.so asks for libamdhip64.so.7 and, loaded first, gets /opt/rocm's copy — a later `import torch` then
+    loads a SECOND runtime under the other file name and finds no GPU ("No HIP GPUs are available").  Loading torch's copy
+    first makes both resolve to it, whichever side is used first.  Skipped when torch is absent or already imported."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("SCTL_AMD_OWN_HIP_RUNTIME") == "1":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    for loc in (spec.submodule_search_locations or []) if spec else []:
+        cand = os.path.join(loc, "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            return
+
+
 def lib():
     """The loaded C-ABI library.  Raises if it has not been built: there is no fallback."""
     global _LIB
@@ -45,6 +66,7 @@ def lib():
     if not os.path.exists(path):
         raise SctlAmdError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
                            "`make -C sctl_amd/csrc` (hipcc, gfx950); sctl_amd has no CPU fallback" % path)
+    _share_torch_hip_runtime()
     L = C.CDLL(path)
     vp, i64, ci = C.c_void_p, C.c_int64, C.c_int
     L.sctl_amd_last_error.restype = C.c_char_p
@@ -60,6 +82,14 @@ def lib():
     L.sctl_amd_counters.argtypes = [C.POINTER(i64), C.POINTER(i64)]
     L.sctl_amd_counters.restype = None
     L.sctl_amd_reset_counters.restype = None
+    L.sctl_amd_trim.restype = None
+    pi64 = C.POINTER(i64)
+    L.sctl_amd_near_create.argtypes = [ci, ci, i64, ci, ci, vp, vp, vp, vp, i64, vp, vp, vp, C.POINTER(vp)]
+    L.sctl_amd_near_apply_host.argtypes = [vp, vp, vp]
+    L.sctl_amd_near_apply_device.argtypes = [vp, vp, vp, vp]
+    L.sctl_amd_near_info.argtypes = [vp, pi64, pi64, pi64, pi64, pi64]
+    L.sctl_amd_near_destroy.argtypes = [vp]
+    L.sctl_amd_near_destroy.restype = None
     L.sctl_amd_eval_plan.argtypes = [ci, ci, i64, i64, i64, ci, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(i64), C.POINTER(i64)]
     L.sctl_amd_eval_path.argtypes = [ci, ci, i64, i64, i64]
     L.sctl_amd_op_create.argtypes = [ci, ci, C.POINTER(C.c_int), ci, C.POINTER(vp)]
@@ -123,6 +153,11 @@ def counters():
 
 def reset_counters():
     lib().sctl_amd_reset_counters()
+
+
+def trim():
+    """Release the device scratch memory cached per (device, stream)."""
+    lib().sctl_amd_trim()
 
 
 def _ctx_blob(info, ctx):
@@ -314,6 +349,61 @@ class DirectOp:
         if self._h:
             lib().sctl_amd_op_destroy(self._h)
             self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class NearOp:
+    """BoundaryIntegralOp::ComputeNearInterac with the operator blocks resident on one GPU (sctl_amd_near_*): built from the
+    arrays SetupNear leaves behind (boundary_integral.txx:816-1012), applied once per solver iteration."""
+
+    def __init__(self, src_dim, trg_dim, elem_nds_cnt, near_elem_cnt, K_near, near_scatter_index, near_trg_cnt, near_trg_dsp, K_near_cnt=None, device=0):
+        i8 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.int64)
+        self._keep = [i8(elem_nds_cnt), i8(near_elem_cnt), i8(K_near_cnt), np.ascontiguousarray(K_near), i8(near_scatter_index), i8(near_trg_cnt), i8(near_trg_dsp)]
+        nds, near, kcnt, K, sc, tc, td = self._keep
+        self.dtype = K.dtype
+        self.real = _real_of(K.dtype)
+        self.device = device
+        h = C.c_void_p()
+        p = lambda a: None if a is None or a.size == 0 else a.ctypes.data_as(C.c_void_p)
+        _check(lib().sctl_amd_near_create(self.real, device, nds.size, src_dim, trg_dim, p(nds), p(near), p(kcnt), p(K), tc.size, p(sc), p(tc), p(td), C.byref(h)),
+               "near_create")
+        self._h = h
+        v = [C.c_int64() for _ in range(5)]
+        _check(lib().sctl_amd_near_info(self._h, *[C.byref(x) for x in v]), "near_info")
+        self.density_len, self.potential_len, self.near_entries, self.operator_bytes, self.workgroups = (x.value for x in v)
+
+    def apply(self, F, U=None):
+        """U += near field of density F (numpy arrays); U=None starts from zero."""
+        F = np.ascontiguousarray(F, dtype=self.dtype)
+        if F.size != self.density_len:
+            raise SctlAmdError("density must hold %d values" % self.density_len)
+        if U is None:
+            U = np.zeros(self.potential_len, dtype=self.dtype)
+        if U.size != self.potential_len or U.dtype != self.dtype or not U.flags.c_contiguous:
+            raise SctlAmdError("potential must be a contiguous %s array of %d values" % (self.dtype, self.potential_len))
+        p = lambda a: None if a.size == 0 else a.ctypes.data_as(C.c_void_p)
+        _check(lib().sctl_amd_near_apply_host(self._h, p(F), p(U)), "near_apply_host")
+        return U
+
+    def apply_device(self, F, U, stream=None):
+        """The same on torch CUDA tensors, enqueued on `stream` (default: torch's current stream); U is accumulated into."""
+        import torch
+        tdt = torch.float64 if self.dtype == np.float64 else torch.float32
+        with torch.cuda.device(F.device):
+            st = stream if stream is not None else torch.cuda.current_stream()
+            _check(lib().sctl_amd_near_apply_device(self._h, _t_ptr(F, tdt, self.density_len, "F"), _t_ptr(U, tdt, self.potential_len, "U"),
+                                                    C.c_void_p(st.cuda_stream)), "near_apply_device")
+        return U
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().sctl_amd_near_destroy(self._h)
+            self._h = None
 
     def __del__(self):
         try:

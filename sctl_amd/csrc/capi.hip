@@ -2,6 +2,7 @@
 // and the one-process multi-GPU driver.  All arithmetic lives in eval_kernel.hpp / ukernels.hpp.
 #include "../../include/sctl_amd.h"
 #include "launch.hpp"
+#include "workspace.hpp"
 
 #include <atomic>
 #include <functional>
@@ -28,6 +29,9 @@ int fail(int code, const std::string& msg) {
   g_err = msg;
   return code;
 }
+}  // namespace
+int set_error(int code, const std::string& msg) { return fail(code, msg); }   // for the other translation units (near.hip)
+namespace {
 #define HIP_TRY(expr)                                                                                        \
   do {                                                                                                       \
     hipError_t e_ = (expr);                                                                                  \
@@ -169,7 +173,7 @@ int eval_device_t(const KernelEntry& k, int real, int64_t Nt, int64_t Ns, const 
   a.chunk = p.chunk; a.scale = (R)k.scale; a.ctx = make_ctx(k, ctx);
   if (p.splits > 1) {
     void* ws = nullptr;
-    HIP_TRY(hipMallocAsync(&ws, (size_t)p.workspace_bytes, st));
+    HIP_TRY(workspace_acquire(st, (size_t)p.workspace_bytes, &ws));   // the block of this stream (workspace.hpp), not the HIP pool
     a.partial = (R*)ws;
   }
   const dim3 grid((unsigned)p.wg_x, (unsigned)p.splits);
@@ -180,7 +184,6 @@ int eval_device_t(const KernelEntry& k, int real, int64_t Nt, int64_t Ns, const 
     hipLaunchKernelGGL((reduce_splits_kernel<R>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, v, (const R*)a.partial, n,
                        p.splits, (R)k.scale);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipFreeAsync(a.partial, st));
   }
   g_pairs += Nt * Ns;
   g_flops += Nt * Ns * k.flops;
@@ -209,7 +212,7 @@ struct DevBuf {
 };
 struct StreamGuard {
   hipStream_t s = nullptr;
-  ~StreamGuard() { if (s) (void)hipStreamDestroy(s); }
+  ~StreamGuard() { if (s) { workspace_forget(s); (void)hipStreamDestroy(s); } }
 };
 
 // Pinned (hipHostMalloc) staging memory for every host<->device transfer of the host-pointer entry points.
@@ -558,7 +561,7 @@ void sctl_amd_op_destroy(sctl_amd_op* op) {
     if (hipSetDevice(d.device) != hipSuccess) { (void)hipGetLastError(); continue; }
     for (void* p : {d.xt, d.xs, d.xn, d.f, d.v})
       if (p) (void)hipFree(p);
-    if (d.st) (void)hipStreamDestroy(d.st);
+    if (d.st) { workspace_forget(d.st); (void)hipStreamDestroy(d.st); }
   }
   delete op;
 }
@@ -644,6 +647,7 @@ void sctl_amd_counters(int64_t* pair_interactions, int64_t* sctl_flops) {
   if (sctl_flops) *sctl_flops = g_flops.load();
 }
 void sctl_amd_reset_counters(void) { g_pairs = 0; g_flops = 0; }
+void sctl_amd_trim(void) { workspace_release_all(); }
 
 int sctl_amd_eval_plan(int kernel, int real, int64_t Nt, int64_t Ns, int64_t Nt_whole, int digits, int* trg_per_lane, int* src_splits,
                        int64_t* workgroups, int64_t* workspace_bytes) {

@@ -1,8 +1,9 @@
 // Host driver of the tile-centred Laplace single-layer path (centered_kernel.hpp): Morton-sort the targets on the device
 // (rocPRIM radix sort of 63-bit keys), evaluate on the sorted order, scatter-add the result back.  Everything is enqueued
-// on the caller's stream; temporaries come from hipMallocAsync and are released with hipFreeAsync.
+// on the caller's stream; temporaries are carved out of the stream's scratch block (workspace.hpp).
 #include "centered_kernel.hpp"
 #include "launch.hpp"
+#include "workspace.hpp"
 
 #include <cstdlib>
 
@@ -17,14 +18,6 @@ namespace sctl_amd {
   } while (0)
 
 namespace {
-struct AsyncBuf {
-  void* p = nullptr;
-  hipStream_t st;
-  explicit AsyncBuf(hipStream_t s) : st(s) {}
-  ~AsyncBuf() { if (p) (void)hipFreeAsync(p, st); }
-  hipError_t alloc(size_t bytes) { return hipMallocAsync(&p, bytes ? bytes : 8, st); }
-};
-
 template <class R, int MODE> void launch_centered(const EvalArgs<R>& a, dim3 grid, hipStream_t st) {
   hipLaunchKernelGGL((laplace_fxu_centered_kernel<R, MODE, 2>), grid, dim3(kWaveBlock), 0, st, a);
 }
@@ -58,46 +51,45 @@ hipError_t eval_laplace_fxu_centered(int64_t Nt, int64_t Ns, const R* xt, const 
   int64_t chunk;
   centered_plan(Nt, Ns, cus, &T, &splits, &chunk);
   const int nblk_box = 256;
-  AsyncBuf part(st), keys(st), keys2(st), idx(st), idx2(st), xts(st), outs(st), tmp(st), partial(st);
-  CENTERED_TRY(part.alloc(sizeof(double) * 6 * nblk_box));
-  CENTERED_TRY(keys.alloc(sizeof(uint64_t) * Nt));
-  CENTERED_TRY(keys2.alloc(sizeof(uint64_t) * Nt));
-  CENTERED_TRY(idx.alloc(sizeof(uint32_t) * Nt));
-  CENTERED_TRY(idx2.alloc(sizeof(uint32_t) * Nt));
-  CENTERED_TRY(xts.alloc(sizeof(R) * 3 * Nt));
-  CENTERED_TRY(outs.alloc(sizeof(R) * Nt));
   const unsigned nb = (unsigned)((Nt + kBlock - 1) / kBlock);
-
-  hipLaunchKernelGGL((bbox_partial_kernel<R>), dim3(nblk_box), dim3(kBlock), 0, st, xt, Nt, (double*)part.p);
-  hipLaunchKernelGGL((morton_keys_kernel<R>), dim3(nb), dim3(kBlock), 0, st, xt, Nt, (const double*)part.p, nblk_box, (uint64_t*)keys.p,
-                     (uint32_t*)idx.p);
-  size_t tmp_bytes = 0;
-  CENTERED_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (uint64_t*)keys.p, (uint64_t*)keys2.p, (uint32_t*)idx.p, (uint32_t*)idx2.p, (size_t)Nt, 0,
+  size_t tmp_bytes = 0;   // size query only: no pointer is dereferenced
+  CENTERED_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)Nt, 0,
                                          63, st));
-  CENTERED_TRY(tmp.alloc(tmp_bytes));
-  CENTERED_TRY(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, (uint64_t*)keys.p, (uint64_t*)keys2.p, (uint32_t*)idx.p, (uint32_t*)idx2.p, (size_t)Nt, 0, 63,
-                                         st));
-  const uint32_t* perm = (const uint32_t*)idx2.p;
-  hipLaunchKernelGGL((gather_points_kernel<R>), dim3(nb), dim3(kBlock), 0, st, xt, perm, Nt, (R*)xts.p);
-  CENTERED_TRY(hipMemsetAsync(outs.p, 0, sizeof(R) * Nt, st));
+  const size_t n = (size_t)Nt;
+  const size_t total = Carver::pad(sizeof(double) * 6 * nblk_box) + 2 * Carver::pad(sizeof(uint64_t) * n) + 2 * Carver::pad(sizeof(uint32_t) * n) +
+                       Carver::pad(sizeof(R) * 3 * n) + Carver::pad(sizeof(R) * n) + Carver::pad(tmp_bytes) +
+                       (splits > 1 ? Carver::pad(sizeof(R) * (size_t)splits * n) : 0);
+  void* base = nullptr;
+  CENTERED_TRY(workspace_acquire(st, total, &base));
+  Carver cut(base);
+  double* part = cut.take<double>(6 * nblk_box);
+  uint64_t *keys = cut.take<uint64_t>(n), *keys2 = cut.take<uint64_t>(n);
+  uint32_t *idx = cut.take<uint32_t>(n), *idx2 = cut.take<uint32_t>(n);
+  R *xts = cut.take<R>(3 * n), *outs = cut.take<R>(n);
+  char* tmp = cut.take<char>(tmp_bytes);
+  R* partial = (splits > 1) ? cut.take<R>((size_t)splits * n) : nullptr;
+
+  hipLaunchKernelGGL((bbox_partial_kernel<R>), dim3(nblk_box), dim3(kBlock), 0, st, xt, Nt, part);
+  hipLaunchKernelGGL((morton_keys_kernel<R>), dim3(nb), dim3(kBlock), 0, st, xt, Nt, (const double*)part, nblk_box, keys, idx);
+  CENTERED_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, idx, idx2, (size_t)Nt, 0, 63, st));
+  const uint32_t* perm = idx2;
+  hipLaunchKernelGGL((gather_points_kernel<R>), dim3(nb), dim3(kBlock), 0, st, xt, perm, Nt, xts);
+  CENTERED_TRY(hipMemsetAsync(outs, 0, sizeof(R) * Nt, st));
 
   EvalArgs<R> a{};
-  a.Nt = Nt; a.Ns = Ns; a.xt = (const R*)xts.p; a.xs = xs; a.xn = nullptr; a.f = f; a.v_trg = (R*)outs.p; a.partial = nullptr;
+  a.Nt = Nt; a.Ns = Ns; a.xt = xts; a.xs = xs; a.xn = nullptr; a.f = f; a.v_trg = outs; a.partial = nullptr;
   a.chunk = chunk; a.scale = scale;
   a.ctx.v[0] = kNearFactor2;
   if (const char* e = std::getenv("SCTL_AMD_EXPERIMENT_NEAR_FACTOR")) a.ctx.v[0] = std::atof(e);   // timing experiments only
-  if (splits > 1) {
-    CENTERED_TRY(partial.alloc(sizeof(R) * (size_t)splits * Nt));
-    a.partial = (R*)partial.p;
-  }
+  a.partial = partial;
   const dim3 grid((unsigned)((Nt + (int64_t)kWaveBlock * T - 1) / ((int64_t)kWaveBlock * T)), (unsigned)splits);
   if (mode == 0) launch_centered<R, 0>(a, grid, st);
   else if (mode == 1) launch_centered<R, 1>(a, grid, st);
   else launch_centered<R, (sizeof(R) == 8 ? 2 : 1)>(a, grid, st);
   CENTERED_TRY(hipGetLastError());
   if (splits > 1)
-    hipLaunchKernelGGL((reduce_splits_kernel<R>), dim3(nb), dim3(kBlock), 0, st, (R*)outs.p, (const R*)a.partial, Nt, splits, scale);
-  hipLaunchKernelGGL((scatter_add_kernel<R>), dim3(nb), dim3(kBlock), 0, st, (const R*)outs.p, perm, Nt, 1, v_trg);
+    hipLaunchKernelGGL((reduce_splits_kernel<R>), dim3(nb), dim3(kBlock), 0, st, outs, (const R*)a.partial, Nt, splits, scale);
+  hipLaunchKernelGGL((scatter_add_kernel<R>), dim3(nb), dim3(kBlock), 0, st, (const R*)outs, perm, Nt, 1, v_trg);
   return hipGetLastError();
 }
 template hipError_t eval_laplace_fxu_centered<double>(int64_t, int64_t, const double*, const double*, const double*, double*, double, int, int, hipStream_t);

@@ -1,0 +1,246 @@
+// BoundaryIntegralOp::ComputeNearInterac on the device: the precomputed per-element near-field
+// operator matrices stay resident in HBM; one application is a batch of small row-major GEMVs U_ = F_ . K_near_
+// (boundary_integral.txx:1092-1102), the permutation by near_scatter_index (:1129) and the per-target accumulation
+// (:1131-1140).  HBM-bound: every byte of K_near is read exactly once per application and nothing else is of that order.
+#include "../../include/sctl_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace sctl_amd {
+int set_error(int code, const std::string& msg);   // capi.hip: records the message for sctl_amd_last_error()
+
+namespace {
+
+#define NEAR_TRY(expr)                                                                                              \
+  do {                                                                                                              \
+    hipError_t e_ = (expr);                                                                                         \
+    if (e_ != hipSuccess) return set_error(SCTL_AMD_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));    \
+  } while (0)
+
+constexpr int kCols = 64;     // columns (target dofs) of an operator block handled by one workgroup: one per lane of a wave
+constexpr int kRowGroups = 4; // the four waves of a workgroup take rows s = g, g + 4, ...
+constexpr int kNearBlock = kCols * kRowGroups;
+
+struct NearWork {   // one workgroup: columns [t0, t0 + 64) of one element's block
+  int64_t k_off;    // first entry of the block in K_near
+  int64_t f_off;    // first density value of the element
+  int64_t u_off;    // first entry of the element's run in U_near
+  int32_t src_dof, trg_dof, t0, pad;
+};
+
+// U_near[u_off + t] = sum_s F[f_off + s] * K[k_off + s * trg_dof + t]: lanes along t (512 contiguous bytes per row and
+// wave in fp64), the waves of the workgroup interleave the rows, four row loads in flight per lane, and the four partial
+// sums are added in wave order (deterministic).
+template <class R>
+__global__ void __launch_bounds__(kNearBlock) near_gemv_kernel(const NearWork* __restrict__ work, const R* __restrict__ K, const R* __restrict__ F,
+                                                               R* __restrict__ U_near) {
+  __shared__ R part[kRowGroups][kCols];
+  const NearWork w = work[blockIdx.x];
+  const int lane = threadIdx.x & (kCols - 1), g = threadIdx.x / kCols;
+  const int t = w.t0 + lane;
+  const bool live = t < w.trg_dof;
+  const R* Kc = K + w.k_off + (live ? t : 0);
+  const R* Fe = F + w.f_off;
+  const int64_t ld = w.trg_dof;
+  R a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  int s = g;
+  for (; s + 3 * kRowGroups < w.src_dof; s += 4 * kRowGroups) {
+    const R k0 = Kc[(int64_t)s * ld], k1 = Kc[(int64_t)(s + kRowGroups) * ld], k2 = Kc[(int64_t)(s + 2 * kRowGroups) * ld],
+            k3 = Kc[(int64_t)(s + 3 * kRowGroups) * ld];
+    a0 += Fe[s] * k0;
+    a1 += Fe[s + kRowGroups] * k1;
+    a2 += Fe[s + 2 * kRowGroups] * k2;
+    a3 += Fe[s + 3 * kRowGroups] * k3;
+  }
+  for (; s < w.src_dof; s += kRowGroups) a0 += Fe[s] * Kc[(int64_t)s * ld];
+  part[g][lane] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (g == 0 && live) U_near[w.u_off + t] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+}
+
+// U[i*k1 + k] += sum over the target's near entries, in the order of the scattered array (boundary_integral.txx:1129-1140)
+template <class R>
+__global__ void __launch_bounds__(256) near_accumulate_kernel(int64_t ntrg, int k1, const int64_t* __restrict__ scatter, const int64_t* __restrict__ trg_cnt,
+                                                              const int64_t* __restrict__ trg_dsp, const R* __restrict__ U_near, R* __restrict__ U) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= ntrg * k1) return;
+  const int64_t i = idx / k1;
+  const int k = (int)(idx - i * k1);
+  const int64_t p0 = trg_dsp[i], p1 = p0 + trg_cnt[i];
+  if (p1 == p0) return;
+  R acc = U[idx];
+  for (int64_t p = p0; p < p1; p++) acc += U_near[scatter[p] * k1 + k];
+  U[idx] = acc;
+}
+
+struct DevMem {
+  void* p = nullptr;
+  ~DevMem() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+};
+struct PinMem {
+  void* p = nullptr;
+  ~PinMem() { if (p) (void)hipHostFree(p); }
+  hipError_t alloc(size_t bytes) { return hipHostMalloc(&p, bytes ? bytes : 8, hipHostMallocPortable); }
+};
+
+}  // namespace
+}  // namespace sctl_amd
+
+using namespace sctl_amd;
+
+struct sctl_amd_near {
+  int real = 0, device = 0, k0 = 0, k1 = 0;
+  int64_t nelem = 0, ntrg = 0, n_near = 0, f_len = 0, k_len = 0, nwork = 0;
+  DevMem K, work, scatter, trg_cnt, trg_dsp, F, U_near, U;
+  PinMem stage;                 // F down, U up (host entry)
+  hipStream_t st = nullptr;
+  ~sctl_amd_near() { if (st) (void)hipStreamDestroy(st); }
+};
+
+namespace {
+
+template <class R>
+int apply_on_stream(sctl_amd_near* h, const R* F, R* U, hipStream_t st) {
+  (void)hipGetLastError();
+  if (h->nwork > 0) {
+    hipLaunchKernelGGL((near_gemv_kernel<R>), dim3((unsigned)h->nwork), dim3(kNearBlock), 0, st, (const NearWork*)h->work.p, (const R*)h->K.p, F,
+                       (R*)h->U_near.p);
+    NEAR_TRY(hipGetLastError());
+  }
+  if (h->n_near > 0 && h->ntrg > 0) {
+    const int64_t n = h->ntrg * h->k1;
+    hipLaunchKernelGGL((near_accumulate_kernel<R>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->ntrg, h->k1, (const int64_t*)h->scatter.p,
+                       (const int64_t*)h->trg_cnt.p, (const int64_t*)h->trg_dsp.p, (const R*)h->U_near.p, U);
+    NEAR_TRY(hipGetLastError());
+  }
+  return SCTL_AMD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sctl_amd_near_create(int real, int device, int64_t Nelem, int src_dim, int trg_dim, const int64_t* elem_nds_cnt, const int64_t* near_elem_cnt,
+                         const int64_t* K_near_cnt, const void* K_near, int64_t Ntrg, const int64_t* near_scatter_index, const int64_t* near_trg_cnt,
+                         const int64_t* near_trg_dsp, sctl_amd_near** out) {
+  if (!out) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "null output handle");
+  *out = nullptr;
+  if (real != SCTL_AMD_F64 && real != SCTL_AMD_F32) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "real must be SCTL_AMD_F64 or SCTL_AMD_F32");
+  if (Nelem < 0 || Ntrg < 0 || src_dim < 1 || trg_dim < 1) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "negative size or non-positive kernel dimension");
+  if (Nelem > 0 && (!elem_nds_cnt || !near_elem_cnt)) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "null element count array");
+  if (Ntrg > 0 && (!near_trg_cnt || !near_trg_dsp)) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "null target count array");
+
+  // displacements (the reference's omp_par::scan, boundary_integral.txx:433,854) and the work list
+  std::vector<NearWork> work;
+  int64_t f_len = 0, n_near = 0, k_len = 0;
+  for (int64_t e = 0; e < Nelem; e++) {
+    const int64_t nds = elem_nds_cnt[e], nt = near_elem_cnt[e];
+    if (nds < 0 || nt < 0) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "negative element count");
+    const int64_t kc = K_near_cnt ? K_near_cnt[e] : nds * nt;
+    if (kc != 0 && kc != nds * nt) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "K_near_cnt[e] must be 0 or elem_nds_cnt[e] * near_elem_cnt[e] (boundary_integral.txx:1097)");
+    const int64_t sd = nds * src_dim, td = nt * trg_dim;
+    if (sd > INT32_MAX || td > INT32_MAX) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "operator block too large");
+    if (kc != 0 && sd > 0 && td > 0)
+      for (int64_t t0 = 0; t0 < td; t0 += kCols) work.push_back(NearWork{k_len * src_dim * trg_dim, f_len, n_near * trg_dim, (int32_t)sd, (int32_t)td, (int32_t)t0, 0});
+    f_len += sd;
+    n_near += nt;
+    k_len += kc;
+  }
+  if (k_len > 0 && !K_near) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "null K_near");
+  if (n_near > 0 && !near_scatter_index) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "null near_scatter_index");
+  int64_t cnt_sum = 0;
+  for (int64_t i = 0; i < Ntrg; i++) {
+    if (near_trg_cnt[i] < 0 || near_trg_dsp[i] < 0 || near_trg_dsp[i] + near_trg_cnt[i] > n_near)
+      return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "near_trg_dsp/cnt outside the near list");
+    cnt_sum += near_trg_cnt[i];
+  }
+  if (cnt_sum != n_near) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "sum of near_trg_cnt differs from sum of near_elem_cnt");
+  for (int64_t p = 0; p < n_near; p++)
+    if (near_scatter_index[p] < 0 || near_scatter_index[p] >= n_near) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "near_scatter_index out of range");
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess) { (void)hipGetLastError(); ndev = 0; }
+  if (ndev <= 0 || device < 0 || device >= ndev) return set_error(SCTL_AMD_ERR_NO_DEVICE, "no HIP device: libsctl_amd has no CPU fallback");
+
+  const size_t rs = (real == SCTL_AMD_F64) ? 8 : 4;
+  std::unique_ptr<sctl_amd_near> h(new sctl_amd_near);
+  h->real = real; h->device = device; h->k0 = src_dim; h->k1 = trg_dim;
+  h->nelem = Nelem; h->ntrg = Ntrg; h->n_near = n_near; h->f_len = f_len; h->k_len = k_len * src_dim * trg_dim; h->nwork = (int64_t)work.size();
+  NEAR_TRY(hipSetDevice(device));
+  NEAR_TRY(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
+  NEAR_TRY(h->K.alloc((size_t)h->k_len * rs));
+  NEAR_TRY(h->work.alloc(work.size() * sizeof(NearWork)));
+  NEAR_TRY(h->scatter.alloc((size_t)n_near * 8));
+  NEAR_TRY(h->trg_cnt.alloc((size_t)Ntrg * 8));
+  NEAR_TRY(h->trg_dsp.alloc((size_t)Ntrg * 8));
+  NEAR_TRY(h->F.alloc((size_t)f_len * rs));
+  NEAR_TRY(h->U_near.alloc((size_t)n_near * trg_dim * rs));
+  NEAR_TRY(h->U.alloc((size_t)Ntrg * trg_dim * rs));
+  NEAR_TRY(h->stage.alloc(((size_t)f_len + (size_t)Ntrg * trg_dim) * rs + 512));
+  // one-time uploads: synchronous copies from the caller's arrays (read once, never rewritten in place by this library)
+  if (h->k_len) NEAR_TRY(hipMemcpy(h->K.p, K_near, (size_t)h->k_len * rs, hipMemcpyHostToDevice));
+  if (!work.empty()) NEAR_TRY(hipMemcpy(h->work.p, work.data(), work.size() * sizeof(NearWork), hipMemcpyHostToDevice));
+  if (n_near) NEAR_TRY(hipMemcpy(h->scatter.p, near_scatter_index, (size_t)n_near * 8, hipMemcpyHostToDevice));
+  if (Ntrg) {
+    NEAR_TRY(hipMemcpy(h->trg_cnt.p, near_trg_cnt, (size_t)Ntrg * 8, hipMemcpyHostToDevice));
+    NEAR_TRY(hipMemcpy(h->trg_dsp.p, near_trg_dsp, (size_t)Ntrg * 8, hipMemcpyHostToDevice));
+  }
+  NEAR_TRY(hipMemset(h->U_near.p, 0, (size_t)n_near * trg_dim * rs));   // runs of matrix-free elements stay zero (:1096)
+  *out = h.release();
+  return SCTL_AMD_OK;
+}
+
+int sctl_amd_near_apply_device(sctl_amd_near* h, const void* F, void* U, void* stream) {
+  if (!h) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "null near-field handle");
+  if ((h->f_len > 0 && !F) || (h->ntrg > 0 && !U)) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "null density or potential array");
+  if (h->real == SCTL_AMD_F64) return apply_on_stream<double>(h, (const double*)F, (double*)U, (hipStream_t)stream);
+  return apply_on_stream<float>(h, (const float*)F, (float*)U, (hipStream_t)stream);
+}
+
+int sctl_amd_near_apply_host(sctl_amd_near* h, const void* F, void* U) {
+  if (!h) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "null near-field handle");
+  if ((h->f_len > 0 && !F) || (h->ntrg > 0 && !U)) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "null density or potential array");
+  if (h->n_near == 0 || h->ntrg == 0) return SCTL_AMD_OK;
+  const size_t rs = (h->real == SCTL_AMD_F64) ? 8 : 4;
+  const size_t bf = (size_t)h->f_len * rs, bu = (size_t)h->ntrg * h->k1 * rs;
+  NEAR_TRY(hipSetDevice(h->device));
+  char* sf = (char*)h->stage.p;
+  char* su = sf + ((bf + 255) & ~(size_t)255);
+  std::memcpy(sf, F, bf);                                  // pinned staging: see capi.hip PinnedBuf
+  NEAR_TRY(hipMemcpyAsync(h->F.p, sf, bf, hipMemcpyHostToDevice, h->st));
+  NEAR_TRY(hipMemsetAsync(h->U.p, 0, bu, h->st));
+  const int rc = sctl_amd_near_apply_device(h, h->F.p, h->U.p, h->st);
+  if (rc != SCTL_AMD_OK) return rc;
+  NEAR_TRY(hipMemcpyAsync(su, h->U.p, bu, hipMemcpyDeviceToHost, h->st));
+  NEAR_TRY(hipStreamSynchronize(h->st));
+  const int64_t n = h->ntrg * h->k1;                       // U += near field (boundary_integral.txx:1131-1140)
+  if (h->real == SCTL_AMD_F64) { double* d = (double*)U; const double* s = (const double*)su; for (int64_t i = 0; i < n; i++) d[i] += s[i]; }
+  else { float* d = (float*)U; const float* s = (const float*)su; for (int64_t i = 0; i < n; i++) d[i] += s[i]; }
+  return SCTL_AMD_OK;
+}
+
+int sctl_amd_near_info(const sctl_amd_near* h, int64_t* density_len, int64_t* potential_len, int64_t* near_entries, int64_t* operator_bytes,
+                       int64_t* workgroups) {
+  if (!h) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "null near-field handle");
+  if (density_len) *density_len = h->f_len;
+  if (potential_len) *potential_len = h->ntrg * h->k1;
+  if (near_entries) *near_entries = h->n_near;
+  if (operator_bytes) *operator_bytes = h->k_len * ((h->real == SCTL_AMD_F64) ? 8 : 4);
+  if (workgroups) *workgroups = h->nwork;
+  return SCTL_AMD_OK;
+}
+
+void sctl_amd_near_destroy(sctl_amd_near* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  delete h;
+}
+
+}  // extern "C"

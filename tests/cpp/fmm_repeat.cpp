@@ -1,0 +1,40 @@
+// Repeated ParticleFMM::Eval on ONE object (an iterative solver's pattern): every evaluation must give bit-identical results.
+// Regression driver for the memory-pool fault described in sctl_amd/csrc/workspace.hpp; run by tests/test_cpp_host.py.
+//   fmm_repeat <N> <evaluations> <microseconds to sleep between evaluations>
+#include <sctl_amd.hpp>
+#include <cstdio>
+#include <cmath>
+#include <vector>
+#include <unistd.h>
+using namespace sctl_amd;
+int main(int argc, char** argv) {
+  const Long N = argc > 1 ? atol(argv[1]) : 3000;
+  const int reps = argc > 2 ? atoi(argv[2]) : 6;
+  Stokes3D_FSxU k_m2l; Stokes3D_FxU k_sl; Stokes3D_DxU k_dl;
+  srand48(0);
+  Vector<double> Xt(N * 3), Xs(N * 3), Xn(N * 3), F(N * 3);
+  for (auto& a : Xt) a = drand48() - 0.5;
+  for (auto& a : Xs) a = drand48() - 0.5;
+  for (auto& a : Xn) a = drand48() - 0.5;
+  for (auto& a : F) a = drand48() - 0.5;
+  ParticleFMM<double, 3> fmm(Comm::World());
+  fmm.SetKernels(k_m2l, k_m2l, k_sl);
+  fmm.AddTrg("T", k_m2l, k_sl); fmm.AddSrc("S", k_dl, k_dl); fmm.SetKernelS2T("S", "T", k_dl);
+  fmm.SetTrgCoord("T", Xt); fmm.SetSrcCoord("S", Xs, Xn); fmm.SetSrcDensity("S", F);
+  std::vector<Vector<double>> U(reps);
+  const int us = argc > 3 ? atoi(argv[3]) : 0;
+  for (int r = 0; r < reps; r++) { fmm.Eval(U[r], "T"); if (us) usleep(us); }
+  const Vector<double>& ref = U[reps - 1];
+  for (int r = 0; r < reps; r++) {
+    long bad = 0, first = -1, last = -1, zero = 0, dbl = 0;
+    for (Long i = 0; i < ref.Dim(); i++)
+      if (U[r][i] != ref[i]) {
+        bad++; if (first < 0) first = i; last = i;
+        if (U[r][i] == 0) zero++;
+        if (std::fabs(U[r][i] - 2 * ref[i]) < 1e-12 * std::fabs(ref[i])) dbl++;
+      }
+    printf("eval %d: %ld of %ld differ, range [%ld, %ld], zeros %ld, doubled %ld\n", r, bad, (long)ref.Dim(), first, last, zero, dbl);
+    if (bad) for (Long i = first; i < first + 4 && i < ref.Dim(); i++) printf("   [%ld] got %.6e expected %.6e\n", (long)i, U[r][i], ref[i]);
+  }
+  return 0;
+}

@@ -70,6 +70,20 @@ def test_particle_fmm_driver_matches_oracle(tmp_path, O):
     assert "flops: %d" % (N * N * (6 * 26 + 3 * 23 + 16) + 33 * 20 * 26) in p.stdout
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,reps,sleep_us", [(3000, 6, 0), (3000, 5, 20000), (5000, 5, 0), (40000, 3, 0)])
+def test_repeated_eval_on_one_object_is_bit_identical(tmp_path, n, reps, sleep_us):
+    """ParticleFMM::Eval several times on one object from a C++ process (which runs on /opt/rocm's HIP runtime, not on the
+    one PyTorch brings): with scratch memory from hipMallocAsync the second evaluation was wrong in half of the runs at
+    N = 3000 and always at N = 5000 (sctl_amd/csrc/workspace.hpp)."""
+    exe = _build(tmp_path, "fmm_repeat")
+    for _ in range(3):
+        p = subprocess.run([exe, str(n), str(reps), str(sleep_us)], capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0, p.stderr
+        lines = [l for l in p.stdout.splitlines() if "differ" in l]
+        assert len(lines) == reps and all(": 0 of" in l for l in lines), p.stdout
+
+
 FAR = [c for c in load_manifest()["cases"] if c["kind"] == "far_field"]
 
 

@@ -1,0 +1,130 @@
+"""BoundaryIntegralOp near field (reference boundary_integral.txx:816-1012 setup, :1079-1142 apply).
+Golden data: tests/golden/near_field.npz, generated from the REAL reference's BoundaryIntegralOp driven with a synthetic
+element list (oracle/gen_golden_near.py).  CPU: the oracle's numpy restatement of ComputeNearInterac reproduces the
+reference's result from the reference's operator arrays, and far field + near field = ComputePotential.  GPU: the device
+routine (sctl_amd_near_*, through the C ABI) does the same."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import sctl_amd
+from conftest import ROOT, rel_l2
+from sctl_amd.rand48 import Rand48
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+CASES = json.load(open(os.path.join(GOLD, "near_manifest.json")))["cases"]
+_NPZ = None
+
+
+def gold(case, key):
+    global _NPZ
+    if _NPZ is None:
+        _NPZ = np.load(os.path.join(GOLD, "near_field.npz"))
+    return _NPZ["%s/%s" % (case["key"], key)]
+
+
+def near_inputs(c, k0):
+    """oracle/gen_golden_near.py:near_inputs — targets, target normals, nodes, node normals, weights, density."""
+    g = Rand48(c["seed"])
+    xt = g.drand48(c["Nt"] * 3) - 0.5
+    xnt = g.drand48(c["Nt"] * 3) - 0.5
+    xs = g.drand48(c["Ns"] * 3) - 0.5
+    xn = g.drand48(c["Ns"] * 3) - 0.5
+    w = g.drand48(c["Ns"]) * 0.01
+    f = g.drand48(c["Ns"] * k0) - 0.5
+    return xt, xnt, xs, xn, w, f
+
+
+def dims(O, c):
+    inf = O.info(c["kernel"])
+    return inf["k0"], (inf["k1"] // 3 if c["trg_normal_dot_prod"] else inf["k1"])
+
+
+IDS = ["%s-%s" % (c["kernel"], c["key"]) for c in CASES]
+
+
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_near_restatement_matches_reference(O, oracle_mod, case):
+    k0, k1 = dims(O, case)
+    xt, xnt, xs, xn, w, f = near_inputs(case, k0)
+    arrs = {k: gold(case, k) for k in ("elem_nds_cnt", "near_elem_cnt", "K_near_cnt", "K_near", "near_scatter_index", "near_trg_cnt", "near_trg_dsp")}
+    assert arrs["near_scatter_index"].size == case["near_entries"] > 0
+    un = oracle_mod.near_apply_restatement(k0, k1, F=f, **arrs)
+    assert rel_l2(un, gold(case, "u_near")) < 1e-15
+    # ComputePotential = ComputeFarField + ComputeNearInterac (boundary_integral.txx:608-614)
+    self_trg = case["Nt"] == 0
+    far = oracle_mod.far_field_restatement(O, case["kernel"], None if self_trg else xt, xn if self_trg else xnt, xs, xn, w, f, bool(case["trg_normal_dot_prod"]))
+    assert rel_l2(far + un, gold(case, "u_total")) < 1e-10        # the reference's far field ran at tol 1e-10
+    # accumulate semantics (:1131-1140)
+    u0 = np.full_like(un, 0.25)
+    assert rel_l2(oracle_mod.near_apply_restatement(k0, k1, F=f, U=u0.copy(), **arrs), un + 0.25) < 1e-15
+
+
+def test_near_symbols_fail_loudly_without_gpu():
+    if sctl_amd.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(sctl_amd.api.SctlAmdError, match="no HIP device"):
+        sctl_amd.NearOp(1, 1, [1], [1], np.ones(1), [0], [1], [0])
+
+
+def test_near_create_rejects_inconsistent_arrays():
+    bad = [dict(K_near_cnt=[3]),                       # block size != nodes x near targets
+           dict(near_trg_cnt=[2]),                     # more entries claimed than the near list holds
+           dict(near_scatter_index=[5])]               # permutation out of range
+    for kw in bad:
+        a = dict(elem_nds_cnt=[2], near_elem_cnt=[1], K_near=np.ones(2), near_scatter_index=[0], near_trg_cnt=[1], near_trg_dsp=[0], K_near_cnt=None)
+        a.update(kw)
+        with pytest.raises(sctl_amd.api.SctlAmdError) as ei:          # argument checks come before the device is touched
+            sctl_amd.NearOp(1, 1, **a)
+        assert "no HIP device" not in str(ei.value)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_near_device_matches_reference(O, case):
+    import torch
+    k0, k1 = dims(O, case)
+    f = near_inputs(case, k0)[5]
+    arrs = {k: gold(case, k) for k in ("elem_nds_cnt", "near_elem_cnt", "K_near_cnt", "K_near", "near_scatter_index", "near_trg_cnt", "near_trg_dsp")}
+    op = sctl_amd.NearOp(k0, k1, **arrs)
+    assert op.near_entries == case["near_entries"] and op.operator_bytes == arrs["K_near"].size * 8 and op.density_len == f.size
+    ref = gold(case, "u_near")
+    u = op.apply(f)
+    assert rel_l2(u, ref) < 1e-14, rel_l2(u, ref)
+    u2 = op.apply(f, U=u.copy())                                   # accumulates
+    assert rel_l2(u2, 2 * ref) < 1e-14
+    fd, ud = torch.from_numpy(f).cuda(), torch.full((ref.size,), 0.5, dtype=torch.float64, device="cuda")
+    op.apply_device(fd, ud)
+    assert rel_l2(ud.cpu().numpy(), ref + 0.5) < 1e-14
+    # fp32 operator against the fp64 reference
+    arrs32 = dict(arrs, K_near=arrs["K_near"].astype(np.float32))
+    u32 = sctl_amd.NearOp(k0, k1, **arrs32).apply(f.astype(np.float32))
+    assert rel_l2(u32.astype(np.float64), ref) < 5e-6
+    op.close()
+
+
+@pytest.mark.gpu
+def test_near_device_large_random_operator(oracle_mod):
+    """Sizes the golden cases do not reach: thousands of elements, blocks wider than one 64-column workgroup and blocks with
+    fewer rows than the workgroup has row groups, empty elements, elements without a matrix, targets without near entries."""
+    rng = np.random.default_rng(17)
+    nelem, ntrg, k0, k1 = 3000, 20000, 3, 3
+    nds = rng.integers(0, 9, nelem)
+    near = rng.integers(0, 120, nelem)
+    near[::97] = 700                                              # a few very wide blocks
+    kcnt = nds * near
+    kcnt[5::11] = 0                                               # matrix-free elements contribute nothing
+    K = rng.standard_normal(int(kcnt.sum()) * k0 * k1)
+    n_near = int(near.sum())
+    trg_of_entry = rng.integers(0, ntrg // 2, n_near)             # the upper half of the targets has no near entries
+    order = np.argsort(trg_of_entry, kind="stable")               # SortScatterIndex: entries grouped by target
+    cnt = np.bincount(trg_of_entry, minlength=ntrg)
+    dsp = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+    F = rng.standard_normal(int(nds.sum()) * k0)
+    ref = oracle_mod.near_apply_restatement(k0, k1, nds, near, kcnt, K, order, cnt, dsp, F)
+    op = sctl_amd.NearOp(k0, k1, nds, near, K, order, cnt, dsp, K_near_cnt=kcnt)
+    u = op.apply(F)
+    assert rel_l2(u, ref) < 1e-14, rel_l2(u, ref)
+    assert np.all(u.reshape(ntrg, k1)[ntrg // 2:] == 0)
