@@ -75,15 +75,76 @@ def read_traffic(workload):
         return None
 
 
+def bench_near(args):
+    """Extra workload: one application of a device-resident near-field operator,
+    BoundaryIntegralOp::ComputeNearInterac (boundary_integral.txx:1079-1142).  HBM-bound: the algorithmic traffic of a step is
+    the bytes of K_near (every operator entry is read once); densities, U_near and the index arrays are < 1 % of that."""
+    import torch
+    import sctl_amd
+    if args.gpus != 1:
+        raise SystemExit("bench.py --workload near_apply runs on one GPU (the operator of a rank is applied where its targets live)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: sctl_amd has no CPU path to measure")
+    nelem, nds, near, k0, k1 = 2048, 48, 400, 3, 3            # Stokes-like: 144 x 1200 blocks, 2.8 GB of fp64 operator
+    rng = np.random.default_rng(0)
+    n_near = nelem * near
+    ntrg = n_near // 8                                         # every target is near ~8 elements
+    K = rng.standard_normal(nelem * nds * k0 * near * k1)
+    trg = rng.integers(0, ntrg, n_near)
+    order = np.argsort(trg, kind="stable")
+    cnt = np.bincount(trg, minlength=ntrg)
+    dsp = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+    op = sctl_amd.NearOp(k0, k1, np.full(nelem, nds), np.full(nelem, near), K, order, cnt, dsp)
+    F = torch.randn(op.density_len, dtype=torch.float64, device="cuda")
+    U = torch.zeros(op.potential_len, dtype=torch.float64, device="cuda")
+    for _ in range(args.warmup):
+        op.apply_device(F, U)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    tic = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        op.apply_device(F, U)
+    e1.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - tic
+    k_ms = e0.elapsed_time(e1) / args.steps
+    entries = op.operator_bytes / 8
+    achieved = op.operator_bytes / (k_ms * 1e-3) / 1e9
+    line = {"metric": "operator entries applied/s, BoundaryIntegralOp near field (ComputeNearInterac)", "value": entries / (elapsed / args.steps),
+            "unit": "matrix-entries/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "near-field operator: %d elements, blocks %d x %d (Stokes-like), %.2f GB of K_near resident in HBM, %d targets" %
+                                   (nelem, nds * k0, near * k1, op.operator_bytes / 1e9, ntrg), "workgroups": op.workgroups},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                         "kernel_ms": k_ms, "note": "algorithmic bytes = sizeof(K_near): 8 B per operator entry, read once per application"}}
+    if not args.no_cpu_baseline:
+        sample = 256                                           # elements; numpy's BLAS GEMV per element, as Matrix::GEMM at :1101
+        Kb = K[:sample * nds * k0 * near * k1].reshape(sample, nds * k0, near * k1)
+        Fh = rng.standard_normal((sample, nds * k0))
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < 5.0:
+            for e in range(sample):
+                Fh[e] @ Kb[e]
+            reps += 1
+        secs = time.perf_counter() - t0
+        line["cpu_baseline"] = {"value": reps * Kb.size / secs, "unit": "matrix-entries/s", "cores": os.cpu_count(), "kind": "port",
+                                "sample": "%d of %d element blocks, numpy (BLAS) GEMV per block, %d repetitions, %.1f s" % (sample, nelem, reps, secs)}
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="laplace_sl", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="laplace_sl", choices=sorted(WORKLOADS) + ["near_apply"])
     ap.add_argument("--digits", type=int, default=-1, help="accuracy request; -1 = full precision (the reference default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.workload == "near_apply":
+        return bench_near(args)
 
     import torch
     import torch.distributed as dist

@@ -27,41 +27,55 @@ constexpr int kCols = 64;     // columns (target dofs) of an operator block hand
 constexpr int kRowGroups = 4; // the four waves of a workgroup take rows s = g, g + 4, ...
 constexpr int kNearBlock = kCols * kRowGroups;
 
-struct NearWork {   // one workgroup: columns [t0, t0 + 64) of one element's block
+struct NearWork {   // one workgroup: columns [t0, t0 + 64) (narrow) or [t0, t0 + 256) (wide) of one element's block
   int64_t k_off;    // first entry of the block in K_near
   int64_t f_off;    // first density value of the element
   int64_t u_off;    // first entry of the element's run in U_near
-  int32_t src_dof, trg_dof, t0, pad;
+  int32_t src_dof, trg_dof, t0, wide;
 };
 
-// U_near[u_off + t] = sum_s F[f_off + s] * K[k_off + s * trg_dof + t]: lanes along t (512 contiguous bytes per row and
-// wave in fp64), the waves of the workgroup interleave the rows, four row loads in flight per lane, and the four partial
-// sums are added in wave order (deterministic).
-template <class R>
-__global__ void __launch_bounds__(kNearBlock) near_gemv_kernel(const NearWork* __restrict__ work, const R* __restrict__ K, const R* __restrict__ F,
-                                                               R* __restrict__ U_near) {
-  __shared__ R part[kRowGroups][kCols];
-  const NearWork w = work[blockIdx.x];
-  const int lane = threadIdx.x & (kCols - 1), g = threadIdx.x / kCols;
-  const int t = w.t0 + lane;
-  const bool live = t < w.trg_dof;
-  const R* Kc = K + w.k_off + (live ? t : 0);
-  const R* Fe = F + w.f_off;
-  const int64_t ld = w.trg_dof;
-  R a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-  int s = g;
-  for (; s + 3 * kRowGroups < w.src_dof; s += 4 * kRowGroups) {
-    const R k0 = Kc[(int64_t)s * ld], k1 = Kc[(int64_t)(s + kRowGroups) * ld], k2 = Kc[(int64_t)(s + 2 * kRowGroups) * ld],
-            k3 = Kc[(int64_t)(s + 3 * kRowGroups) * ld];
-    a0 += Fe[s] * k0;
-    a1 += Fe[s + kRowGroups] * k1;
-    a2 += Fe[s + 2 * kRowGroups] * k2;
-    a3 += Fe[s + 3 * kRowGroups] * k3;
+// rows s0, s0 + step, ... of one column: UNR row loads in flight per lane.  K_near is read exactly once per application:
+// non-temporal loads keep it from displacing F and U_near in L2.
+template <class R, int UNR>
+__device__ __forceinline__ R near_column_sum(const R* __restrict__ Kc, const R* __restrict__ Fe, int64_t ld, int s0, int step, int src_dof) {
+  R acc[UNR];
+#pragma unroll
+  for (int u = 0; u < UNR; u++) acc[u] = 0;
+  for (int s = s0; s < src_dof; s += UNR * step) {
+    R kv[UNR], fv[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; u++) {
+      const int r = s + u * step;              // wave-uniform
+      const bool ok = r < src_dof;
+      kv[u] = ok ? __builtin_nontemporal_load(Kc + (int64_t)r * ld) : R(0);
+      fv[u] = ok ? Fe[r] : R(0);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; u++) acc[u] += fv[u] * kv[u];
   }
-  for (; s < w.src_dof; s += kRowGroups) a0 += Fe[s] * Kc[(int64_t)s * ld];
-  part[g][lane] = (a0 + a1) + (a2 + a3);
-  __syncthreads();
-  if (g == 0 && live) U_near[w.u_off + t] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+  static_assert(UNR == 8, "pairwise reduction below is written for 8 partial sums");
+  return ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+}
+
+// U_near[u_off + t] = sum_s F[f_off + s] * K[k_off + s * trg_dof + t], lanes along t, every lane walks all rows of its
+// column (no reduction across lanes: deterministic).
+//   wide   (blocks at least 256 columns wide): one work item per workgroup, whose 256 lanes read 2 KB of a row at a time;
+//   narrow : one work item (64 columns) per WAVE; the four waves of a workgroup take four consecutive items.
+// A workgroup walks the work list with the stride of the grid, so small blocks do not pay a workgroup launch each.
+template <class R>
+__global__ void __launch_bounds__(kNearBlock) near_gemv_kernel(const NearWork* __restrict__ wide_work, int64_t n_wide, const NearWork* __restrict__ narrow_work,
+                                                               int64_t n_narrow, const R* __restrict__ K, const R* __restrict__ F, R* __restrict__ U_near) {
+  for (int64_t wi = blockIdx.x; wi < n_wide; wi += gridDim.x) {
+    const NearWork w = wide_work[wi];
+    const int t = w.t0 + (int)threadIdx.x;
+    if (t < w.trg_dof) U_near[w.u_off + t] = near_column_sum<R, 8>(K + w.k_off + t, F + w.f_off, w.trg_dof, 0, 1, w.src_dof);
+  }
+  const int lane = threadIdx.x & (kCols - 1), wave = threadIdx.x / kCols;
+  for (int64_t wi = (int64_t)blockIdx.x * kRowGroups + wave; wi < n_narrow; wi += (int64_t)gridDim.x * kRowGroups) {
+    const NearWork w = narrow_work[wi];
+    const int t = w.t0 + lane;
+    if (t < w.trg_dof) U_near[w.u_off + t] = near_column_sum<R, 8>(K + w.k_off + t, F + w.f_off, w.trg_dof, 0, 1, w.src_dof);
+  }
 }
 
 // U[i*k1 + k] += sum over the target's near entries, in the order of the scattered array (boundary_integral.txx:1129-1140)
@@ -75,7 +89,13 @@ __global__ void __launch_bounds__(256) near_accumulate_kernel(int64_t ntrg, int 
   const int64_t p0 = trg_dsp[i], p1 = p0 + trg_cnt[i];
   if (p1 == p0) return;
   R acc = U[idx];
-  for (int64_t p = p0; p < p1; p++) acc += U_near[scatter[p] * k1 + k];
+  int64_t p = p0;
+  for (; p + 4 <= p1; p += 4) {      // four independent index loads, then four independent gathers, added in list order
+    const int64_t i0 = scatter[p], i1 = scatter[p + 1], i2 = scatter[p + 2], i3 = scatter[p + 3];
+    const R v0 = U_near[i0 * k1 + k], v1 = U_near[i1 * k1 + k], v2 = U_near[i2 * k1 + k], v3 = U_near[i3 * k1 + k];
+    acc = (((acc + v0) + v1) + v2) + v3;
+  }
+  for (; p < p1; p++) acc += U_near[scatter[p] * k1 + k];
   U[idx] = acc;
 }
 
@@ -96,9 +116,10 @@ struct PinMem {
 using namespace sctl_amd;
 
 struct sctl_amd_near {
-  int real = 0, device = 0, k0 = 0, k1 = 0;
+  int real = 0, device = 0, k0 = 0, k1 = 0, cus = 256;
   int64_t nelem = 0, ntrg = 0, n_near = 0, f_len = 0, k_len = 0, nwork = 0;
-  DevMem K, work, scatter, trg_cnt, trg_dsp, F, U_near, U;
+  DevMem K, work, scatter, trg_cnt, trg_dsp, F, U_near, U;   // work: the wide items, then the narrow ones
+  int64_t n_wide = 0, n_narrow = 0;
   PinMem stage;                 // F down, U up (host entry)
   hipStream_t st = nullptr;
   ~sctl_amd_near() { if (st) (void)hipStreamDestroy(st); }
@@ -110,7 +131,11 @@ template <class R>
 int apply_on_stream(sctl_amd_near* h, const R* F, R* U, hipStream_t st) {
   (void)hipGetLastError();
   if (h->nwork > 0) {
-    hipLaunchKernelGGL((near_gemv_kernel<R>), dim3((unsigned)h->nwork), dim3(kNearBlock), 0, st, (const NearWork*)h->work.p, (const R*)h->K.p, F,
+    const int64_t resident = (int64_t)h->cus * 8;   // 8 workgroups of 4 waves fill a CU
+    const int64_t groups = h->n_wide + (h->n_narrow + kRowGroups - 1) / kRowGroups;
+    const unsigned grid = (unsigned)(groups < resident * 4 ? groups : resident * 4);
+    const NearWork* wl = (const NearWork*)h->work.p;
+    hipLaunchKernelGGL((near_gemv_kernel<R>), dim3(grid), dim3(kNearBlock), 0, st, wl, h->n_wide, wl + h->n_wide, h->n_narrow, (const R*)h->K.p, F,
                        (R*)h->U_near.p);
     NEAR_TRY(hipGetLastError());
   }
@@ -138,7 +163,7 @@ int sctl_amd_near_create(int real, int device, int64_t Nelem, int src_dim, int t
   if (Ntrg > 0 && (!near_trg_cnt || !near_trg_dsp)) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "null target count array");
 
   // displacements (the reference's omp_par::scan, boundary_integral.txx:433,854) and the work list
-  std::vector<NearWork> work;
+  std::vector<NearWork> work, narrow;
   int64_t f_len = 0, n_near = 0, k_len = 0;
   for (int64_t e = 0; e < Nelem; e++) {
     const int64_t nds = elem_nds_cnt[e], nt = near_elem_cnt[e];
@@ -147,12 +172,19 @@ int sctl_amd_near_create(int real, int device, int64_t Nelem, int src_dim, int t
     if (kc != 0 && kc != nds * nt) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "K_near_cnt[e] must be 0 or elem_nds_cnt[e] * near_elem_cnt[e] (boundary_integral.txx:1097)");
     const int64_t sd = nds * src_dim, td = nt * trg_dim;
     if (sd > INT32_MAX || td > INT32_MAX) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "operator block too large");
-    if (kc != 0 && sd > 0 && td > 0)
-      for (int64_t t0 = 0; t0 < td; t0 += kCols) work.push_back(NearWork{k_len * src_dim * trg_dim, f_len, n_near * trg_dim, (int32_t)sd, (int32_t)td, (int32_t)t0, 0});
+    if (kc != 0 && sd > 0 && td > 0) {
+      const bool wide = td >= kNearBlock;   // a last wide chunk narrower than 64 columns would idle three waves: it goes narrow
+      int64_t t0 = 0;
+      for (; wide && t0 + kCols <= td && (td - t0 >= kNearBlock || (td - t0) > kNearBlock - kCols); t0 += kNearBlock)
+        work.push_back(NearWork{k_len * src_dim * trg_dim, f_len, n_near * trg_dim, (int32_t)sd, (int32_t)td, (int32_t)t0, 1});
+      for (; t0 < td; t0 += kCols) narrow.push_back(NearWork{k_len * src_dim * trg_dim, f_len, n_near * trg_dim, (int32_t)sd, (int32_t)td, (int32_t)t0, 0});
+    }
     f_len += sd;
     n_near += nt;
     k_len += kc;
   }
+  const int64_t n_wide = (int64_t)work.size(), n_narrow = (int64_t)narrow.size();
+  work.insert(work.end(), narrow.begin(), narrow.end());
   if (k_len > 0 && !K_near) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "null K_near");
   if (n_near > 0 && !near_scatter_index) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "null near_scatter_index");
   int64_t cnt_sum = 0;
@@ -172,9 +204,10 @@ int sctl_amd_near_create(int real, int device, int64_t Nelem, int src_dim, int t
   const size_t rs = (real == SCTL_AMD_F64) ? 8 : 4;
   std::unique_ptr<sctl_amd_near> h(new sctl_amd_near);
   h->real = real; h->device = device; h->k0 = src_dim; h->k1 = trg_dim;
-  h->nelem = Nelem; h->ntrg = Ntrg; h->n_near = n_near; h->f_len = f_len; h->k_len = k_len * src_dim * trg_dim; h->nwork = (int64_t)work.size();
+  h->nelem = Nelem; h->ntrg = Ntrg; h->n_near = n_near; h->f_len = f_len; h->k_len = k_len * src_dim * trg_dim; h->nwork = (int64_t)work.size(); h->n_wide = n_wide; h->n_narrow = n_narrow;
   NEAR_TRY(hipSetDevice(device));
   NEAR_TRY(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
+  { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) h->cus = n; }
   NEAR_TRY(h->K.alloc((size_t)h->k_len * rs));
   NEAR_TRY(h->work.alloc(work.size() * sizeof(NearWork)));
   NEAR_TRY(h->scatter.alloc((size_t)n_near * 8));
