@@ -117,6 +117,15 @@ int sctl_amd_kernel_matrix_device(int kernel, int real, int64_t Nt, int64_t Ns, 
 int sctl_amd_kernel_matrix_host(int kernel, int real, int64_t Nt, int64_t Ns, const void* r_trg, const void* r_src,
                                 const void* n_src, void* M, int digits, const void* ctx, int ctx_bytes, int device);
 
+/* Many operator blocks in one launch: block b = KernelMatrix of targets [sum(Nt[:b]), +Nt[b]) of r_trg against sources
+ * [sum(Ns[:b]), +Ns[b]) of r_src / n_src, stored (Ns[b]*SrcDim) x (Nt[b]*TrgDim) row-major; the blocks are concatenated in
+ * M in batch order.  This is the shape of BoundaryIntegralOp::SetupNear's direct-part subtraction, which calls KernelMatrix
+ * once per element on that element's near targets and far-field nodes (boundary_integral.txx:946-1009, Xtrg_near by
+ * near_elem_dsp, X_far by elem_nds_dsp_far): one call here replaces that loop.  HOST arrays. */
+int sctl_amd_kernel_matrix_batch_host(int kernel, int real, int64_t nbatch, const int64_t* Nt, const int64_t* Ns, const void* r_trg,
+                                      const void* r_src, const void* n_src, void* M, int digits, const void* ctx, int ctx_bytes,
+                                      int device);
+
 /* ---- device-resident operator: coordinates stay on the GPUs between evaluations ------------------------------- */
 /* The MI355X-first form of what ParticleFMM keeps between SetSrcCoord/SetTrgCoord and repeated Eval calls
  * (fmm-wrapper.txx:444-479: the object owns copies of X, Xn, F; boundary_integral.txx:1054,1063: an iterative solver

@@ -16,8 +16,8 @@
 //     SetupNear   near lists (BuildNearList, :46-468), K_near from K_self / NearInterac (:860-942), minus the direct
 //                 far-field quadrature through KernelMatrix and FarFieldDensityOperatorTranspose (:944-1009)
 //     ComputeNearInterac   U_ = F_ K_near_ per element, scatter, accumulate          boundary_integral.txx:1079-1142
-// Here the setup runs on the host (it calls the user's element-list code; the direct part comes from the device
-// KernelMatrix) and the application runs on the device: the assembled arrays go to sctl_amd_near_create once and every
+// Here the setup runs on the host (it calls the user's element-list code; the direct part comes from ONE batched device
+// KernelMatrix launch per element list) and the application runs on the device: the assembled arrays go to sctl_amd_near_create once and every
 // ComputeNearInterac is one sctl_amd_near_apply_host.  The near list is built for ONE rank with a uniform cell grid
 // instead of the reference's distributed Morton tree; it yields the same lists (element-major, targets ascending).
 // Matrix-free element lists (EvalNearInterac) are evaluated on the host, as in the reference.
@@ -456,6 +456,25 @@ template <class Real, class Kernel> class BoundaryIntegralOp {
       const ElementListBase<Real>* elem_lst = elem_lst_map.at(elem_lst_name[i]);
       if (elem_lst->MatrixFree()) continue;
       const ElemData& fn = elem_data_map.at(elem_lst_name[i]);
+      // The direct far-field quadrature of every element of this list at its own near targets, in ONE device launch: block j
+      // is what the reference gets from KernelMatrix(Mker, Xtrg_near_, X, Xn) for element j (:971,986).
+      Vector<Real> Mfull_all;
+      Vector<Long> blk_nt(elem_lst_cnt[i]), blk_ns(elem_lst_cnt[i]), blk_dsp(elem_lst_cnt[i]);
+      if (elem_lst_cnt[i]) {
+        const Long e0 = elem_lst_dsp[i], e1 = e0 + elem_lst_cnt[i];
+        Long off = 0;
+        for (Long e = e0; e < e1; e++) {
+          blk_nt[e - e0] = near_elem_cnt[e];
+          blk_ns[e - e0] = elem_nds_cnt_far[e];
+          blk_dsp[e - e0] = off;
+          off += elem_nds_cnt_far[e] * KDIM0 * near_elem_cnt[e] * KDIM1;
+        }
+        const Long t0 = near_elem_dsp[e0], t1 = near_elem_dsp[e1 - 1] + near_elem_cnt[e1 - 1];
+        const Long s0 = elem_nds_dsp_far[e0], s1 = elem_nds_dsp_far[e1 - 1] + elem_nds_cnt_far[e1 - 1];
+        const Vector<Real> Xt_((t1 - t0) * COORD_DIM, Xtrg_near.begin() + t0 * COORD_DIM, false);
+        const Vector<Real> Xs_((s1 - s0) * COORD_DIM, X_far.begin() + s0 * COORD_DIM, false), Xn_((s1 - s0) * COORD_DIM, Xn_far.begin() + s0 * COORD_DIM, false);
+        ker_.template KernelMatrixBatch<Real, true>(Mfull_all, blk_nt, blk_ns, Xt_, Xs_, Xn_);
+      }
       for (Long j = 0; j < elem_lst_cnt[i]; j++) {
         const Long e = elem_lst_dsp[i] + j, nt = near_elem_cnt[e], nds = elem_nds_cnt[e], N0 = nds * KDIM0;
         if (!nt || !nds) continue;
@@ -486,12 +505,9 @@ template <class Real, class Kernel> class BoundaryIntegralOp {
           }
         }
         {  // minus what the far-field quadrature of this element already contributes at these targets (:944-1009)
-          const Vector<Real> Xt_(nt * COORD_DIM, Xtrg_near.begin() + near_elem_dsp[e] * COORD_DIM, false);
           const Long ns = elem_nds_cnt_far[e], s0 = elem_nds_dsp_far[e];
-          const Vector<Real> X_(ns * COORD_DIM, X_far.begin() + s0 * COORD_DIM, false), Xn_(ns * COORD_DIM, Xn_far.begin() + s0 * COORD_DIM, false);
           Matrix<Real> Mker(ns * KDIM0, nt * KDIM1_);
-          Matrix<Real> Mfull;
-          ker_.template KernelMatrix<Real, true>(Mfull, Xt_, X_, Xn_);   // on the device, full precision
+          const Matrix<Real> Mfull(ns * KDIM0, nt * KDIM1, Mfull_all.begin() + blk_dsp[j], false);   // computed on the device, full precision
           for (Long sidx = 0; sidx < ns; sidx++)
             for (Long k0 = 0; k0 < KDIM0; k0++)
               for (Long t = 0; t < nt; t++)

@@ -83,6 +83,27 @@ template <class uKernel> class GenericKernel : public uKernel {
     CheckStatus(rc, "sctl_amd_kernel_matrix_host");
   }
 
+  // Many operator blocks in one device launch (not in the reference, whose SetupNear calls KernelMatrix once per element,
+  // boundary_integral.txx:946-1009): block b pairs targets [sum(Nt[:b]), +Nt[b]) of Xt with sources [sum(Ns[:b]), +Ns[b])
+  // of Xs/Xn and is stored like a KernelMatrix result, (Ns[b]*SrcDim) x (Nt[b]*TrgDim) row-major; blocks are concatenated in M.
+  template <class Real, bool enable_openmp = false, Integer digits = -1>
+  void KernelMatrixBatch(Vector<Real>& M, const Vector<Long>& Nt, const Vector<Long>& Ns, const Vector<Real>& Xt, const Vector<Real>& Xs, const Vector<Real>& Xn) const {
+    static_assert(sizeof(Long) == sizeof(int64_t), "Long must be 64 bits wide");
+    SCTL_AMD_ASSERT(Nt.Dim() == Ns.Dim());
+    Long nt = 0, ns = 0, m = 0;
+    for (Long b = 0; b < Nt.Dim(); b++) { nt += Nt[b]; ns += Ns[b]; m += Ns[b] * KDIM0 * Nt[b] * KDIM1; }
+    SCTL_AMD_ASSERT(Xt.Dim() == nt * DIM);
+    SCTL_AMD_ASSERT(Xs.Dim() == ns * DIM);
+    SCTL_AMD_ASSERT(Xn.Dim() == ns * N_DIM || !N_DIM);
+    if (M.Dim() != m) M.ReInit(m);
+    if (!m) return;
+    RequireSupported();
+    const int rc = sctl_amd_kernel_matrix_batch_host(DeviceKernelId(), RealTag<Real>::value, Nt.Dim(), reinterpret_cast<const int64_t*>(&Nt[0]),
+                                                     reinterpret_cast<const int64_t*>(&Ns[0]), Xt.begin(), Xs.begin(), N_DIM ? Xn.begin() : nullptr, M.begin(),
+                                                     (int)digits, ctx_ptr, (int)uKernel::CTX_BYTES, DeviceSet::Get()[0]);
+    CheckStatus(rc, "sctl_amd_kernel_matrix_batch_host");
+  }
+
  private:
   static void RequireSupported() {
     if (!IsSupported()) {

@@ -22,7 +22,7 @@ KERNEL_NAMES = ["Laplace3D-FxU", "Laplace3D-DxU", "Laplace3D-FxdU", "Stokes3D-Fx
 # every symbol include/sctl_amd.h declares (tests/test_boundary.py checks the header against this list and the .so)
 SYMBOLS = ["sctl_amd_version", "sctl_amd_last_error", "sctl_amd_device_count", "sctl_amd_kernel_id", "sctl_amd_kernel_name",
            "sctl_amd_kernel_info", "sctl_amd_flops_per_pair", "sctl_amd_eval_device", "sctl_amd_eval_device_slab", "sctl_amd_eval_host", "sctl_amd_eval_host_multi",
-           "sctl_amd_kernel_matrix_device", "sctl_amd_kernel_matrix_host", "sctl_amd_counters", "sctl_amd_reset_counters", "sctl_amd_trim",
+           "sctl_amd_kernel_matrix_device", "sctl_amd_kernel_matrix_host", "sctl_amd_kernel_matrix_batch_host", "sctl_amd_counters", "sctl_amd_reset_counters", "sctl_amd_trim",
            "sctl_amd_eval_plan", "sctl_amd_eval_path", "sctl_amd_op_create", "sctl_amd_op_set_targets",
            "sctl_amd_op_set_sources", "sctl_amd_op_eval", "sctl_amd_op_destroy", "sctl_amd_near_create", "sctl_amd_near_apply_host",
            "sctl_amd_near_apply_device", "sctl_amd_near_info", "sctl_amd_near_destroy"]
@@ -79,6 +79,7 @@ def lib():
     L.sctl_amd_eval_host_multi.argtypes = [ci, ci, i64, i64, vp, vp, vp, vp, vp, ci, vp, ci, C.POINTER(C.c_int), ci]
     L.sctl_amd_kernel_matrix_device.argtypes = [ci, ci, i64, i64, vp, vp, vp, vp, ci, vp, ci, vp]
     L.sctl_amd_kernel_matrix_host.argtypes = [ci, ci, i64, i64, vp, vp, vp, vp, ci, vp, ci, ci]
+    L.sctl_amd_kernel_matrix_batch_host.argtypes = [ci, ci, i64, vp, vp, vp, vp, vp, vp, ci, vp, ci, ci]
     L.sctl_amd_counters.argtypes = [C.POINTER(i64), C.POINTER(i64)]
     L.sctl_amd_counters.restype = None
     L.sctl_amd_reset_counters.restype = None
@@ -249,6 +250,23 @@ def kernel_matrix_host(name, r_trg, r_src, n_src, digits=-1, ctx=None, device=0)
                                              _np_ptr(n_src, dt, Ns * info["nd"], "n_src"), _np_ptr(M, dt, M.size, "M"), digits, cp, cb, device),
            "kernel_matrix_host")
     return M
+
+
+def kernel_matrix_batch_host(name, Nt, Ns, r_trg, r_src, n_src, digits=-1, ctx=None, device=0):
+    """Many KernelMatrix blocks in one launch (sctl_amd_kernel_matrix_batch_host): returns the list of (Ns[b]*K0, Nt[b]*K1) blocks."""
+    info = kernel_info(name)
+    dt = r_trg.dtype
+    real = _real_of(dt)
+    Nt, Ns = np.ascontiguousarray(Nt, dtype=np.int64), np.ascontiguousarray(Ns, dtype=np.int64)
+    sizes = Ns * info["k0"] * Nt * info["k1"]
+    M = np.zeros(int(sizes.sum()), dtype=dt)
+    keep, cp, cb = _ctx_blob(info, ctx)
+    _check(lib().sctl_amd_kernel_matrix_batch_host(info["id"], real, Nt.size, Nt.ctypes.data_as(C.c_void_p), Ns.ctypes.data_as(C.c_void_p),
+                                                   _np_ptr(r_trg, dt, int(Nt.sum()) * 3, "r_trg"), _np_ptr(r_src, dt, int(Ns.sum()) * 3, "r_src"),
+                                                   _np_ptr(n_src, dt, int(Ns.sum()) * info["nd"], "n_src"), _np_ptr(M, dt, M.size, "M"), digits, cp, cb, device),
+           "kernel_matrix_batch_host")
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    return [M[off[b]:off[b + 1]].reshape(int(Ns[b]) * info["k0"], int(Nt[b]) * info["k1"]) for b in range(Nt.size)]
 
 
 def kernel_matrix_device(name, r_trg, r_src, n_src, M=None, digits=-1, ctx=None, stream=None):

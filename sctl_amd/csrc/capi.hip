@@ -530,6 +530,67 @@ int sctl_amd_kernel_matrix_host(int kernel, int real, int64_t Nt, int64_t Ns, co
 }
 
 
+int sctl_amd_kernel_matrix_batch_host(int kernel, int real, int64_t nbatch, const int64_t* Nt, const int64_t* Ns, const void* r_trg, const void* r_src,
+                                      const void* n_src, void* M, int digits, const void* ctx, int ctx_bytes, int device) {
+  const KernelEntry* k = registry(kernel);
+  if (!k) return fail(SCTL_AMD_ERR_UNKNOWN_KERNEL, "unknown kernel id");
+  if (real != SCTL_AMD_F64 && real != SCTL_AMD_F32) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "real must be SCTL_AMD_F64 or SCTL_AMD_F32");
+  if (nbatch < 0 || (nbatch > 0 && (!Nt || !Ns))) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "negative batch count or null size arrays");
+  if (k->ctx_bytes != 0 && (ctx_bytes != k->ctx_bytes || !ctx))
+    return fail(SCTL_AMD_ERR_BAD_CONTEXT, std::string(k->name) + " needs a context blob of " + std::to_string(k->ctx_bytes) + " bytes");
+  std::vector<MatTile> tiles;
+  int64_t nt_all = 0, ns_all = 0, m_all = 0;
+  for (int64_t b = 0; b < nbatch; b++) {
+    if (Nt[b] < 0 || Ns[b] < 0 || Nt[b] > INT32_MAX || Ns[b] > INT32_MAX) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "block size out of range");
+    if (Nt[b] > 0 && Ns[b] > 0)
+      for (int64_t t0 = 0; t0 < Nt[b]; t0 += 64) tiles.push_back(MatTile{nt_all, ns_all, m_all, (int32_t)Nt[b], (int32_t)Ns[b], (int32_t)t0, 0});
+    nt_all += Nt[b];
+    ns_all += Ns[b];
+    m_all += Ns[b] * k->k0 * Nt[b] * k->k1;
+  }
+  if ((nt_all > 0 && !r_trg) || (ns_all > 0 && !r_src)) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "null coordinate array");
+  if (ns_all > 0 && k->nd > 0 && !n_src) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, std::string(k->name) + " needs source normals (n_src is null)");
+  if (m_all > 0 && !M) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "null matrix array");
+  const int avail = device_count_quiet();
+  if (avail <= 0) return fail(SCTL_AMD_ERR_NO_DEVICE, "no HIP device: libsctl_amd has no CPU fallback");
+  if (device < 0 || device >= avail) return fail(SCTL_AMD_ERR_NO_DEVICE, "device index out of range");
+  if (tiles.empty()) return SCTL_AMD_OK;
+  if (tiles.size() > 0x7fffffffu) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "too many tiles for one launch");
+  const size_t rs = (real == SCTL_AMD_F64) ? 8 : 4;
+  HIP_TRY(hipSetDevice(device));
+  HostSlot& hs = host_slot(device);
+  if (!hs.st.s) HIP_TRY(hipStreamCreateWithFlags(&hs.st.s, hipStreamNonBlocking));
+  struct Release { HostSlot& h; ~Release() { h.trim((size_t)64 << 20); } } release{hs};
+  const size_t b_xt = (size_t)nt_all * 3 * rs, b_xs = (size_t)ns_all * 3 * rs, b_xn = (size_t)ns_all * k->nd * rs, b_tiles = tiles.size() * sizeof(MatTile),
+               b_m = (size_t)m_all * rs;
+  HIP_TRY(hs.buf[0].reserve(b_xt));
+  HIP_TRY(hs.buf[1].reserve(b_xs));
+  HIP_TRY(hs.buf[2].reserve(b_xn));
+  HIP_TRY(hs.buf[3].reserve(b_tiles));
+  HIP_TRY(hs.buf[4].reserve(b_m));
+  HIP_TRY(hs.stage.reserve(pad256(b_xt) + pad256(b_xs) + pad256(b_xn) + pad256(b_tiles)));
+  HIP_TRY(upload(hs.buf[0].p, r_trg, b_xt, hs.stage, hs.st.s));
+  HIP_TRY(upload(hs.buf[1].p, r_src, b_xs, hs.stage, hs.st.s));
+  if (k->nd) HIP_TRY(upload(hs.buf[2].p, n_src, b_xn, hs.stage, hs.st.s));
+  HIP_TRY(upload(hs.buf[3].p, tiles.data(), b_tiles, hs.stage, hs.st.s));
+  (void)hipGetLastError();
+  const int mode = mode_for(real, digits);
+  if (real == SCTL_AMD_F64)
+    k->matrix_batch_f64[mode]((const MatTile*)hs.buf[3].p, (int64_t)tiles.size(), (const double*)hs.buf[0].p, (const double*)hs.buf[1].p, (const double*)hs.buf[2].p,
+                              (double*)hs.buf[4].p, k->scale, make_ctx(*k, ctx), hs.st.s);
+  else
+    k->matrix_batch_f32[mode]((const MatTile*)hs.buf[3].p, (int64_t)tiles.size(), (const float*)hs.buf[0].p, (const float*)hs.buf[1].p, (const float*)hs.buf[2].p,
+                              (float*)hs.buf[4].p, (float)k->scale, make_ctx(*k, ctx), hs.st.s);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(M, hs.buf[4].p, b_m, hipMemcpyDeviceToHost, hs.st.s));   // M is written once by this call: no staging needed for a D2H
+  HIP_TRY(hipStreamSynchronize(hs.st.s));
+  int64_t pairs = 0;
+  for (int64_t b = 0; b < nbatch; b++) pairs += Nt[b] * Ns[b];
+  g_pairs += pairs;
+  g_flops += pairs * k->flops;
+  return SCTL_AMD_OK;
+}
+
 int sctl_amd_op_create(int kernel, int real, const int* devices, int n_devices, sctl_amd_op** out) {
   const KernelEntry* k = registry(kernel);
   if (!k) return fail(SCTL_AMD_ERR_UNKNOWN_KERNEL, "unknown kernel id");

@@ -240,3 +240,49 @@ __global__ void __launch_bounds__(kBlock) matrix_kernel(int64_t Nt, int64_t Ns, 
 }
 
 }  // namespace sctl_amd
+
+namespace sctl_amd {
+
+// Many small operator blocks in ONE launch (BoundaryIntegralOp::SetupNear builds one block per element,
+// boundary_integral.txx:946-1009): a workgroup takes a tile of 64 targets of one block, its four waves interleave the
+// sources.  Block b is stored like a single KernelMatrix result, (Ns_b*K0) x (Nt_b*K1) row-major, at entry offset m_off.
+struct MatTile {
+  int64_t t_off, s_off, m_off;   // first target / first source of the block in the concatenated coordinate arrays; first entry of the block
+  int32_t nt, ns, t0, pad;
+};
+template <class Ker, class R, int MODE>
+__global__ void __launch_bounds__(kBlock) matrix_batch_kernel(const MatTile* __restrict__ tiles, const R* xt, const R* xs, const R* xn, R* M, R scale, KerCtx ctx) {
+  constexpr int K0 = Ker::K0, K1 = Ker::K1, ND = Ker::ND, NREC = Ker::NREC;
+  using KC = typename Ker::template Consts<R>;
+  __shared__ double kscratch[KC::LDS_DOUBLES > 0 ? KC::LDS_DOUBLES : 1];
+  const KC K(kscratch);
+  const MatTile w = tiles[blockIdx.x];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t = w.t0 + lane;
+  if (t >= w.nt) return;
+  R x_t[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) x_t[k] = xt[(w.t_off + t) * 3 + k];
+  for (int s = wave; s < w.ns; s += kBlock / 64) {
+    R x[3], n[3] = {0, 0, 0}, d[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { x[k] = xs[(w.s_off + s) * 3 + k]; d[k] = x_t[k] - x[k]; }
+#pragma unroll
+    for (int k = 0; k < ND; k++) n[k] = xn[(w.s_off + s) * ND + k];
+#pragma unroll
+    for (int k0 = 0; k0 < K0; k0++) {
+      R f[K0], rec[NREC], acc[K1];
+#pragma unroll
+      for (int k = 0; k < K0; k++) f[k] = (k == k0) ? R(1) : R(0);
+#pragma unroll
+      for (int k = 0; k < K1; k++) acc[k] = 0;
+      Ker::template pack<R>(rec, x, n, f);
+      Ker::template pair<R, MODE, true>(acc, d, rec, ctx, K);
+      R* row = M + w.m_off + (((int64_t)s * K0 + k0) * w.nt + t) * K1;
+#pragma unroll
+      for (int k = 0; k < K1; k++) row[k] = acc[k] * scale;
+    }
+  }
+}
+
+}  // namespace sctl_amd

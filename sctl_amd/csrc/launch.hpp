@@ -10,6 +10,7 @@ constexpr int kTvalues[kNumT] = {1, 2, 4};
 constexpr int kNumMode = 3;                    // rsqrt refinement: seed, Newton, Halley (ukernels.hpp)
 
 template <class R> using EvalLaunch = void (*)(const EvalArgs<R>&, dim3 grid, hipStream_t);
+template <class R> using MatrixBatchLaunch = void (*)(const MatTile* tiles, int64_t ntiles, const R* xt, const R* xs, const R* xn, R* M, R scale, const KerCtx&, hipStream_t);
 template <class R> using MatrixLaunch = void (*)(int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* xn, R* M, R scale, const KerCtx&, dim3 grid, hipStream_t);
 
 struct KernelEntry {
@@ -20,6 +21,8 @@ struct KernelEntry {
   EvalLaunch<float> eval_f32[kNumMode][kNumT];     // modes 0 and 1 only (mode 2 aliases mode 1)
   MatrixLaunch<double> matrix_f64[kNumMode];
   MatrixLaunch<float> matrix_f32[kNumMode];
+  MatrixBatchLaunch<double> matrix_batch_f64[kNumMode];
+  MatrixBatchLaunch<float> matrix_batch_f32[kNumMode];
 };
 
 template <class Ker, class R, int MODE, int T> void launch_eval(const EvalArgs<R>& a, dim3 grid, hipStream_t st) {
@@ -28,6 +31,11 @@ template <class Ker, class R, int MODE, int T> void launch_eval(const EvalArgs<R
 template <class Ker, class R, int MODE> void launch_matrix(int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* xn, R* M, R scale,
                                                            const KerCtx& ctx, dim3 grid, hipStream_t st) {
   hipLaunchKernelGGL((matrix_kernel<Ker, R, MODE>), grid, dim3(kBlock), 0, st, Nt, Ns, xt, xs, xn, M, scale, ctx);
+}
+
+template <class Ker, class R, int MODE> void launch_matrix_batch(const MatTile* tiles, int64_t ntiles, const R* xt, const R* xs, const R* xn, R* M, R scale,
+                                                                 const KerCtx& ctx, hipStream_t st) {
+  hipLaunchKernelGGL((matrix_batch_kernel<Ker, R, MODE>), dim3((unsigned)ntiles), dim3(kBlock), 0, st, tiles, xt, xs, xn, M, scale, ctx);
 }
 
 template <class Ker> KernelEntry make_entry(int ctx_bytes) {
@@ -41,6 +49,10 @@ template <class Ker> KernelEntry make_entry(int ctx_bytes) {
 #undef SCTL_AMD_ROW
   e.matrix_f64[0] = launch_matrix<Ker, double, 0>; e.matrix_f64[1] = launch_matrix<Ker, double, 1>; e.matrix_f64[2] = launch_matrix<Ker, double, 2>;
   e.matrix_f32[0] = launch_matrix<Ker, float, 0>; e.matrix_f32[1] = launch_matrix<Ker, float, 1>; e.matrix_f32[2] = launch_matrix<Ker, float, 1>;
+  e.matrix_batch_f64[0] = launch_matrix_batch<Ker, double, 0>; e.matrix_batch_f64[1] = launch_matrix_batch<Ker, double, 1>;
+  e.matrix_batch_f64[2] = launch_matrix_batch<Ker, double, 2>;
+  e.matrix_batch_f32[0] = launch_matrix_batch<Ker, float, 0>; e.matrix_batch_f32[1] = launch_matrix_batch<Ker, float, 1>;
+  e.matrix_batch_f32[2] = launch_matrix_batch<Ker, float, 1>;
   return e;
 }
 

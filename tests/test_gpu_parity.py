@@ -267,3 +267,28 @@ def test_helmholtz_wavenumbers(O, k, shape):
     # |Re k| r of 1e4 amplifies the rounding of r itself (relative 1e-16) to an absolute phase error of 1e-12
     tol = 1e-12 if abs(k[0]) < 1e3 else 1e-10
     assert rel_l2(u, ref) <= tol, rel_l2(u, ref)
+
+
+@pytest.mark.parametrize("name", ["Laplace3D-FxU", "Stokes3D-DxU", "Laplace3D-FDxUdU", "Helmholtz3D-FxU"])
+def test_kernel_matrix_batch_matches_per_block_oracle(O, name):
+    """sctl_amd_kernel_matrix_batch_host: many operator blocks in one launch == KernelMatrix per block (generic-kernel.txx:191-307),
+    including empty blocks, blocks narrower than one 64-target tile and blocks spanning several tiles."""
+    inf = O.info(name)
+    rng = np.random.default_rng(3)
+    nt = np.array([1, 70, 0, 64, 5, 200, 33], dtype=np.int64)
+    ns = np.array([3, 9, 4, 0, 130, 17, 1], dtype=np.int64)
+    xt, xs = rng.random(int(nt.sum()) * 3), rng.random(int(ns.sum()) * 3)
+    xn = rng.random(int(ns.sum()) * inf["nd"]) - 0.5
+    ctx = np.array([7.5, 0.3]) if name.startswith("Helmholtz") else None
+    blocks = sctl_amd.api.kernel_matrix_batch_host(name, nt, ns, xt, xs, xn, ctx=ctx)
+    to, so = np.concatenate([[0], np.cumsum(nt)]), np.concatenate([[0], np.cumsum(ns)])
+    for b in range(nt.size):
+        assert blocks[b].shape == (ns[b] * inf["k0"], nt[b] * inf["k1"])
+        if blocks[b].size == 0:
+            continue
+        ref = O.kernel_matrix(name, xt[to[b] * 3:to[b + 1] * 3].copy(), xs[so[b] * 3:so[b + 1] * 3].copy(),
+                              xn[so[b] * inf["nd"]:so[b + 1] * inf["nd"]].copy() if inf["nd"] else None, ctx=ctx)
+        assert rel_l2(blocks[b], ref) <= 1e-13, (b, rel_l2(blocks[b], ref))
+    # fp32
+    b32 = sctl_amd.api.kernel_matrix_batch_host(name, nt, ns, xt.astype(np.float32), xs.astype(np.float32), xn.astype(np.float32), ctx=ctx)
+    assert rel_l2(b32[5].astype(np.float64), blocks[5]) <= 1e-5
