@@ -130,8 +130,9 @@ int sctl_amd_kernel_matrix_batch_host(int kernel, int real, int64_t nbatch, cons
 /* The MI355X-first form of what ParticleFMM keeps between SetSrcCoord/SetTrgCoord and repeated Eval calls
  * (fmm-wrapper.txx:444-479: the object owns copies of X, Xn, F; boundary_integral.txx:1054,1063: an iterative solver
  * changes only the density between evaluations).  Coordinates are uploaded once — targets block-partitioned over the
- * device list with the formula of fmm-wrapper.txx:507, sources replicated — and every sctl_amd_op_eval moves only the
- * density down and the potential up.  A handle may be used from one thread at a time. */
+ * device list with the formula of fmm-wrapper.txx:507 (with more than one device the blocks are cut from the Morton order
+ * of the targets; results always come back in the caller's order), sources replicated — and every sctl_amd_op_eval moves
+ * only the density down and the potential up.  A handle may be used from one thread at a time. */
 typedef struct sctl_amd_op sctl_amd_op;
 int sctl_amd_op_create(int kernel, int real, const int* devices, int n_devices, sctl_amd_op** op);
 /* HOST arrays, copied to the devices before returning; either may be called again at any time (new coordinates). */

@@ -4,6 +4,7 @@
 #include "launch.hpp"
 #include "workspace.hpp"
 
+#include <algorithm>
 #include <atomic>
 #include <functional>
 #include <memory>
@@ -366,10 +367,48 @@ struct sctl_amd_op {
   int real = 0;
   int64_t Nt = 0, Ns = 0;
   std::vector<sctl_amd::OpDevice> devs;
+  // several devices: the slabs are cut from the Morton order of the targets, so that a device's targets keep the
+  // density of the whole set (what the tile-centred path needs); perm[i] = caller's index of sorted target i
+  std::vector<int64_t> perm;
 };
 
 namespace sctl_amd {
 namespace {
+
+// Morton order of host points (21 bits per dimension of their bounding box, ties by index): the host-side counterpart of
+// sctl_amd/distributed.py:morton_order.
+template <class R>
+void morton_permutation(const R* x, int64_t n, std::vector<int64_t>& perm) {
+  perm.resize((size_t)n);
+  if (n == 0) return;
+  double lo[3] = {(double)x[0], (double)x[1], (double)x[2]}, hi[3] = {lo[0], lo[1], lo[2]};
+  for (int64_t i = 0; i < n; i++)
+    for (int k = 0; k < 3; k++) { const double v = (double)x[i * 3 + k]; if (v < lo[k]) lo[k] = v; if (v > hi[k]) hi[k] = v; }
+  double span = 0;
+  for (int k = 0; k < 3; k++) if (hi[k] - lo[k] > span) span = hi[k] - lo[k];
+  const double inv = (span > 0) ? 2097152.0 / span : 0.0;
+  auto spread = [](uint64_t v) {
+    v = (v | (v << 32)) & 0x1F00000000FFFFull;
+    v = (v | (v << 16)) & 0x1F0000FF0000FFull;
+    v = (v | (v << 8)) & 0x100F00F00F00F00Full;
+    v = (v | (v << 4)) & 0x10C30C30C30C30C3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
+    return v;
+  };
+  std::vector<std::pair<uint64_t, int64_t>> keyed((size_t)n);
+  for (int64_t i = 0; i < n; i++) {
+    uint64_t key = 0;
+    for (int k = 0; k < 3; k++) {
+      double q = ((double)x[i * 3 + k] - lo[k]) * inv;
+      if (!(q >= 0)) q = 0;                       // also catches NaN
+      if (q > 2097151.0) q = 2097151.0;
+      key |= spread((uint64_t)q) << k;
+    }
+    keyed[(size_t)i] = std::make_pair(key, i);
+  }
+  std::sort(keyed.begin(), keyed.end());
+  for (int64_t i = 0; i < n; i++) perm[(size_t)i] = keyed[(size_t)i].second;
+}
 
 int op_for_each_device(sctl_amd_op* op, const std::function<int(OpDevice&)>& fn) {
   const int n = (int)op->devs.size();
@@ -460,22 +499,17 @@ int sctl_amd_eval_host_multi(int kernel, int real, int64_t Nt, int64_t Ns, const
     if (devs[g] < 0 || devs[g] >= avail) return fail(SCTL_AMD_ERR_NO_DEVICE, "device index " + std::to_string(devs[g]) + " out of range");
   }
   if (n_devices == 1) return eval_host_slab(*k, real, 0, Nt, Ns, r_trg, r_src, n_src, v_src, v_trg, digits, ctx, devs[0]);
-  // contiguous target slabs [Nt*g/G, Nt*(g+1)/G) (fmm-wrapper.txx:507), one host thread and one stream per GPU;
-  // slabs of v_trg are disjoint, so the threads share nothing but read-only inputs
-  std::vector<int> rcs(n_devices, SCTL_AMD_OK);
-  std::vector<std::string> msgs(n_devices);
-  std::vector<std::thread> th;
-  for (int g = 0; g < n_devices; g++) {
-    th.emplace_back([&, g] {
-      const int64_t t0 = Nt * g / n_devices, t1 = Nt * (g + 1) / n_devices;
-      rcs[g] = eval_host_slab(*k, real, t0, t1, Ns, r_trg, r_src, n_src, v_src, v_trg, digits, ctx, devs[g]);
-      if (rcs[g]) msgs[g] = g_err;
-    });
-  }
-  for (auto& t : th) t.join();
-  for (int g = 0; g < n_devices; g++)
-    if (rcs[g]) return fail(rcs[g], "device " + std::to_string(devs[g]) + ": " + msgs[g]);
-  return SCTL_AMD_OK;
+  // several GPUs: the device-resident operator does it (Morton-ordered target slabs with the rank formula of
+  // fmm-wrapper.txx:507, sources replicated, one host thread and one stream per GPU), used once
+  sctl_amd_op* op = nullptr;
+  rc = sctl_amd_op_create(kernel, real, devs.data(), n_devices, &op);
+  if (rc == SCTL_AMD_OK) rc = sctl_amd_op_set_targets(op, Nt, r_trg);
+  if (rc == SCTL_AMD_OK) rc = sctl_amd_op_set_sources(op, Ns, r_src, n_src);
+  if (rc == SCTL_AMD_OK && Nt > 0 && Ns > 0) rc = sctl_amd_op_eval(op, v_src, v_trg, /*accumulate*/ 1, digits, ctx, ctx_bytes);
+  const std::string msg = g_err;
+  sctl_amd_op_destroy(op);
+  if (rc != SCTL_AMD_OK) g_err = msg;
+  return rc;
 }
 
 int sctl_amd_eval_host(int kernel, int real, int64_t Nt, int64_t Ns, const void* r_trg, const void* r_src, const void* n_src,
@@ -634,12 +668,22 @@ int sctl_amd_op_set_targets(sctl_amd_op* op, int64_t Nt, const void* r_trg) {
   op->Nt = Nt;
   int g = 0;
   for (OpDevice& d : op->devs) { d.t0 = Nt * g / G; d.t1 = Nt * (g + 1) / G; g++; }   // fmm-wrapper.txx:507
+  // several devices: slabs of the Morton-ordered targets (coordinates gathered into sorted order once, here)
+  std::vector<char> sorted;
+  op->perm.clear();
+  if (G > 1 && Nt > 0) {
+    if (op->real == SCTL_AMD_F64) morton_permutation((const double*)r_trg, Nt, op->perm);
+    else morton_permutation((const float*)r_trg, Nt, op->perm);
+    sorted.resize((size_t)Nt * 3 * rs);
+    for (int64_t i = 0; i < Nt; i++) std::memcpy(&sorted[(size_t)i * 3 * rs], (const char*)r_trg + (size_t)op->perm[(size_t)i] * 3 * rs, 3 * rs);
+  }
+  const char* src = sorted.empty() ? (const char*)r_trg : sorted.data();
   return op_for_each_device(op, [&](OpDevice& d) -> int {
     const size_t bytes = (size_t)(d.t1 - d.t0) * 3 * rs;
     HIP_TRY(hipSetDevice(d.device));
     HIP_TRY(grow(&d.xt, &d.cap_xt, bytes));
     HIP_TRY(d.stage.reserve(pad256(bytes)));
-    HIP_TRY(upload(d.xt, (const char*)r_trg + (size_t)d.t0 * 3 * rs, bytes, d.stage, d.st));
+    HIP_TRY(upload(d.xt, src + (size_t)d.t0 * 3 * rs, bytes, d.stage, d.st));
     HIP_TRY(hipStreamSynchronize(d.st));
     return SCTL_AMD_OK;
   });
@@ -683,15 +727,27 @@ int sctl_amd_op_eval(sctl_amd_op* op, const void* v_src, void* v_trg, int accumu
     int rc;
     if (op->real == SCTL_AMD_F64)
       rc = eval_device_t<double>(k, op->real, nt, Ns, (const double*)d.xt, (const double*)d.xs, (const double*)d.xn, (const double*)d.f, (double*)d.v,
-                                 digits, ctx, d.st);
+                                 digits, ctx, d.st, op->perm.empty() ? 0 : op->Nt);
     else
       rc = eval_device_t<float>(k, op->real, nt, Ns, (const float*)d.xt, (const float*)d.xs, (const float*)d.xn, (const float*)d.f, (float*)d.v, digits,
-                                ctx, d.st);
+                                ctx, d.st, op->perm.empty() ? 0 : op->Nt);
     if (rc) return rc;
     char* dst = (char*)v_trg + (size_t)d.t0 * k.k1 * rs;
     const char* out = d.stage.take(vbytes);
     HIP_TRY(hipMemcpyAsync((void*)out, d.v, vbytes, hipMemcpyDeviceToHost, d.st));
     HIP_TRY(hipStreamSynchronize(d.st));
+    if (!op->perm.empty()) {   // Morton slab -> the caller's target order (a permutation: the device threads write disjoint entries)
+      const int64_t* perm = op->perm.data() + d.t0;
+      const int k1 = k.k1;
+      if (op->real == SCTL_AMD_F64) {
+        double* o = (double*)v_trg; const double* sv = (const double*)out;
+        for (int64_t i = 0; i < nt; i++) for (int c = 0; c < k1; c++) { double& e = o[perm[i] * k1 + c]; e = (accumulate ? e : 0.0) + sv[i * k1 + c]; }
+      } else {
+        float* o = (float*)v_trg; const float* sv = (const float*)out;
+        for (int64_t i = 0; i < nt; i++) for (int c = 0; c < k1; c++) { float& e = o[perm[i] * k1 + c]; e = (accumulate ? e : 0.0f) + sv[i * k1 + c]; }
+      }
+      return SCTL_AMD_OK;
+    }
     if (!accumulate) {
       std::memcpy(dst, out, vbytes);
       return SCTL_AMD_OK;

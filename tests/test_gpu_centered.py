@@ -118,3 +118,28 @@ def test_compact_slab_uses_the_centred_path_and_matches(O):
         assert rel_l2(u[sel], ref) <= 1e-12
     with pytest.raises(sctl_amd.api.SctlAmdError):
         sctl_amd.eval_device("Laplace3D-FxU", slab, xs, None, f, nt_whole=n - 1)         # a slab larger than its whole
+
+
+def test_one_process_multi_device_slabs_follow_the_morton_curve(O):
+    """sctl_amd_eval_host_multi / sctl_amd_op_* with several devices (the same GPU listed twice on a one-GPU box): slabs are
+    cut from the Morton order, evaluated with the slab hint (tile-centred path at 2^17 targets per device out of 2^18), and
+    the potential comes back in the caller's order; accumulate and overwrite semantics hold; fp32 too."""
+    rng = np.random.default_rng(41)
+    n, ns = 1 << 18, 70001
+    xt, xs, f = rng.random(n * 3), rng.random(ns * 3), rng.random(ns) - 0.5
+    one = sctl_amd.eval_host("Laplace3D-FxU", xt, xs, None, f)
+    two = sctl_amd.eval_host("Laplace3D-FxU", xt, xs, None, f, devices=[0, 0])
+    assert rel_l2(two, one) <= 2e-14, rel_l2(two, one)
+    sel = rng.choice(n, 200, replace=False)
+    ref = O.eval("Laplace3D-FxU", xt.reshape(n, 3)[sel].ravel().copy(), xs, None, f)
+    assert rel_l2(two[sel], ref) <= 1e-12
+    op = sctl_amd.DirectOp("Laplace3D-FxU", np.float64, devices=(0, 0, 0))
+    op.set_targets(xt)
+    op.set_sources(xs)
+    u = np.full(n, 0.5)
+    op.eval(f, u, accumulate=True)
+    assert rel_l2(u - 0.5, one) <= 1e-13
+    op.eval(f, u, accumulate=False)                      # EvalDirect: overwrite
+    assert rel_l2(u, one) <= 2e-14
+    three32 = sctl_amd.eval_host("Laplace3D-FxU", xt.astype(np.float32), xs.astype(np.float32), None, f.astype(np.float32), devices=[0, 0, 0])
+    assert rel_l2(three32[sel].astype(np.float64), ref) <= 1e-4
