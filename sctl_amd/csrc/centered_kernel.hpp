@@ -21,7 +21,12 @@
 
 namespace sctl_amd {
 
-constexpr double kNearFactor2 = 9.0;   // near  <=>  |x_s - c|^2 <= kNearFactor2 * Rt^2
+// near  <=>  |x_s - c|^2 <= kNearFactor2 * Rt^2.  A far source is at least (sqrt(kNearFactor2) - 1) Rt from every target of the
+// wave, so the cancellation in r^2 = |x_t'|^2 + |x_s'|^2 - 2 x_t'.x_s' amplifies rounding by at most
+// (1 + kNearFactor2) / (sqrt(kNearFactor2) - 1)^2 = 5 for the value 4.  Measured on 2^20 x 2^20 uniform points
+// (tools/near_factor.py, profiles/r01c_near_factor.txt): 16 -> 473.6 ms, 9 -> 463.5, 4 -> 455.3, 2.25 -> 454.1, with the
+// rel-L2 distance to the exact kernel flat at 2.2e-15; 4 takes most of the gain with a bounded amplification.
+constexpr double kNearFactor2 = 4.0;
 
 template <class R> __device__ __forceinline__ R wave_min(R v) {
   for (int o = 32; o > 0; o >>= 1) { const R w = __shfl_xor(v, o); v = (w < v) ? w : v; }
