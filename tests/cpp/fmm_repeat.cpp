@@ -1,40 +1,64 @@
 // Repeated ParticleFMM::Eval on ONE object (an iterative solver's pattern): every evaluation must give bit-identical results.
-// Regression driver for the memory-pool fault described in sctl_amd/csrc/workspace.hpp; run by tests/test_cpp_host.py.
-//   fmm_repeat <N> <evaluations> <microseconds to sleep between evaluations>
+// Regression driver for the memory-pool fault described in sctl_amd/csrc/workspace.hpp; run by tests/test_cpp_host.py.  A C++
+// process runs on /opt/rocm's HIP runtime (Python processes run on the one PyTorch brings), so this is also where the
+// tile-centred Laplace path (rocPRIM sort, scratch arena) is exercised on that runtime.
+//   fmm_repeat <N> <evaluations> <microseconds to sleep between evaluations> [stokes|laplace] [<out.bin>: last result]
 #include <sctl_amd.hpp>
-#include <cstdio>
 #include <cmath>
-#include <vector>
+#include <cstdio>
+#include <string>
 #include <unistd.h>
+#include <vector>
 using namespace sctl_amd;
-int main(int argc, char** argv) {
-  const Long N = argc > 1 ? atol(argv[1]) : 3000;
-  const int reps = argc > 2 ? atoi(argv[2]) : 6;
-  Stokes3D_FSxU k_m2l; Stokes3D_FxU k_sl; Stokes3D_DxU k_dl;
+
+template <class KerS2T, class KerAux> int run(Long N, int reps, int us, const char* out) {
+  KerAux k_aux;
+  KerS2T k_s2t;
   srand48(0);
-  Vector<double> Xt(N * 3), Xs(N * 3), Xn(N * 3), F(N * 3);
+  Vector<double> Xt(N * 3), Xs(N * 3), Xn(N * 3), F(N * k_s2t.SrcDim());
   for (auto& a : Xt) a = drand48() - 0.5;
   for (auto& a : Xs) a = drand48() - 0.5;
   for (auto& a : Xn) a = drand48() - 0.5;
   for (auto& a : F) a = drand48() - 0.5;
   ParticleFMM<double, 3> fmm(Comm::World());
-  fmm.SetKernels(k_m2l, k_m2l, k_sl);
-  fmm.AddTrg("T", k_m2l, k_sl); fmm.AddSrc("S", k_dl, k_dl); fmm.SetKernelS2T("S", "T", k_dl);
-  fmm.SetTrgCoord("T", Xt); fmm.SetSrcCoord("S", Xs, Xn); fmm.SetSrcDensity("S", F);
+  fmm.SetAccuracy(16);                       // full precision
+  fmm.SetKernels(k_aux, k_aux, k_aux);
+  fmm.AddTrg("T", k_aux, k_aux);
+  fmm.AddSrc("S", k_s2t, k_s2t);
+  fmm.SetKernelS2T("S", "T", k_s2t);
+  fmm.SetTrgCoord("T", Xt);
+  fmm.SetSrcCoord("S", Xs, Xn);
+  fmm.SetSrcDensity("S", F);
   std::vector<Vector<double>> U(reps);
-  const int us = argc > 3 ? atoi(argv[3]) : 0;
-  for (int r = 0; r < reps; r++) { fmm.Eval(U[r], "T"); if (us) usleep(us); }
+  for (int r = 0; r < reps; r++) {
+    fmm.Eval(U[r], "T");
+    if (us) usleep(us);
+  }
   const Vector<double>& ref = U[reps - 1];
   for (int r = 0; r < reps; r++) {
     long bad = 0, first = -1, last = -1, zero = 0, dbl = 0;
     for (Long i = 0; i < ref.Dim(); i++)
       if (U[r][i] != ref[i]) {
-        bad++; if (first < 0) first = i; last = i;
+        bad++;
+        if (first < 0) first = i;
+        last = i;
         if (U[r][i] == 0) zero++;
         if (std::fabs(U[r][i] - 2 * ref[i]) < 1e-12 * std::fabs(ref[i])) dbl++;
       }
     printf("eval %d: %ld of %ld differ, range [%ld, %ld], zeros %ld, doubled %ld\n", r, bad, (long)ref.Dim(), first, last, zero, dbl);
-    if (bad) for (Long i = first; i < first + 4 && i < ref.Dim(); i++) printf("   [%ld] got %.6e expected %.6e\n", (long)i, U[r][i], ref[i]);
+    if (bad)
+      for (Long i = first; i < first + 4 && i < ref.Dim(); i++) printf("   [%ld] got %.6e expected %.6e\n", (long)i, U[r][i], ref[i]);
   }
+  if (out) ref.Write(out);
   return 0;
+}
+
+int main(int argc, char** argv) {
+  const Long N = argc > 1 ? atol(argv[1]) : 3000;
+  const int reps = argc > 2 ? atoi(argv[2]) : 6;
+  const int us = argc > 3 ? atoi(argv[3]) : 0;
+  const std::string which = argc > 4 ? argv[4] : "stokes";
+  const char* out = argc > 5 ? argv[5] : nullptr;
+  if (which == "laplace") return run<Laplace3D_FxU, Laplace3D_FxU>(N, reps, us, out);
+  return run<Stokes3D_DxU, Stokes3D_FxU>(N, reps, us, out);
 }

@@ -84,6 +84,31 @@ def test_repeated_eval_on_one_object_is_bit_identical(tmp_path, n, reps, sleep_u
         assert len(lines) == reps and all(": 0 of" in l for l in lines), p.stdout
 
 
+@pytest.mark.gpu
+def test_centred_path_from_a_cpp_process(tmp_path, O):
+    """Laplace single layer at 2^18 points through ParticleFMM from C++ (tile-centred path on /opt/rocm's runtime): repeated
+    evaluations bit-identical, equal to the exact kernel (SCTL_AMD_CENTERED=0) to rounding, and right against the oracle."""
+    exe = _build(tmp_path, "fmm_repeat")
+    n = 1 << 18
+    outs = {}
+    for tag, env in (("centred", {}), ("exact", {"SCTL_AMD_CENTERED": "0"})):
+        out = str(tmp_path / (tag + ".bin"))
+        p = subprocess.run([exe, str(n), "3", "0", "laplace", out], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+        assert p.returncode == 0, p.stderr
+        lines = [l for l in p.stdout.splitlines() if "differ" in l]
+        assert len(lines) == 3 and all(": 0 of" in l for l in lines), p.stdout
+        outs[tag] = _read_vector(out)
+    assert rel_l2(outs["centred"], outs["exact"]) <= 2e-14
+    g = Rand48(0)
+    xt = g.drand48(n * 3) - 0.5
+    xs = g.drand48(n * 3) - 0.5
+    g.drand48(n * 3)                                      # the driver also draws (unused) normals
+    f = g.drand48(n) - 0.5
+    sel = np.arange(0, n, n // 256)
+    ref = O.eval("Laplace3D-FxU", xt.reshape(n, 3)[sel].ravel().copy(), xs, None, f)
+    assert rel_l2(outs["centred"][sel], ref) <= 1e-12
+
+
 FAR = [c for c in load_manifest()["cases"] if c["kind"] == "far_field"]
 
 
