@@ -146,11 +146,14 @@ bool use_centered(const KernelEntry& k, int real, int64_t Nt, int64_t Ns, int64_
   const bool enabled = !(e && e[0] == '0'), forced = (e && e[0] == '1');
   if (!enabled || k.id != SCTL_AMD_LAPLACE3D_FXU || Nt >= (int64_t(1) << 32)) return false;
   if (forced) return Nt >= 128 && Ns >= 64;
-  // What decides is the target DENSITY: with fewer than 2^18 targets in the domain the 128 targets of a wave span so much
-  // of it that > 10 % of the sources are "near" and the exact kernel wins (measured at Nt = 2^17, Ns = 2^20: 67.8 ms vs
-  // 65.7 ms; one target per lane does not help: 66.6 ms).  A compact slab of 2^17 out of 2^20 has the density of the
-  // whole set and gains like it (59.4 ms against 64.7 ms exact, tools/slab_locality.py).
-  return (Nt > nt_whole ? Nt : nt_whole) >= (1 << 18) && Nt >= (1 << 17) && Ns >= 65536;
+  // What decides is the target DENSITY: with too few targets in the domain the 128 targets of a wave span so much of it
+  // that many sources are "near" and the exact kernel wins.  Measured with the near threshold 4 Rt^2 (tools/centred_threshold.py,
+  // profiles/r01d_centred_threshold.txt; fp64, exact vs centred): 2^18 x 2^18 34.4 vs 32.1 ms, 2^20 x 2^14 8.69 vs 8.38 ms,
+  // 2^17 x 2^20 67.7 vs 65.6 ms, but 2^17 x 2^17 8.51 vs 8.88 ms and 2^16 x 2^20 34.96 vs 35.15 ms.  A compact slab of 2^17 out
+  // of 2^20 has the density of the whole set and gains like it (59.4 ms against 64.7 ms exact, tools/slab_locality.py).
+  const int64_t dens = Nt > nt_whole ? Nt : nt_whole;
+  if (dens >= (1 << 18)) return Nt >= (1 << 17) && Ns >= (Nt >= (1 << 18) ? (1 << 14) : (1 << 16));
+  return Nt >= (1 << 17) && Ns >= (1 << 20);
 }
 
 template <class R>
