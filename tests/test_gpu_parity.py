@@ -292,3 +292,45 @@ def test_kernel_matrix_batch_matches_per_block_oracle(O, name):
     # fp32
     b32 = sctl_amd.api.kernel_matrix_batch_host(name, nt, ns, xt.astype(np.float32), xs.astype(np.float32), xn.astype(np.float32), ctx=ctx)
     assert rel_l2(b32[5].astype(np.float64), blocks[5]) <= 1e-5
+
+
+def test_host_entries_are_reentrant(O):
+    """The reference calls KernelMatrix inside `omp parallel for` (boundary_integral.txx:949-986) and Eval from whatever thread
+    the caller is on: concurrent host-pointer calls from several threads (each gets its own stream, device buffers and pinned
+    staging; the scratch arena is keyed by stream) must all be right."""
+    import threading
+    rng = np.random.default_rng(23)
+    jobs, results, errors = [], {}, []
+    for i in range(8):
+        name = ("Stokes3D-DxU", "Laplace3D-FxU", "Helmholtz3D-FxU", "Laplace3D-FxdU")[i % 4]
+        info = sctl_amd.kernel_info(name)
+        nt, ns = 700 + 97 * i, 3000 + 501 * i                       # several source splits: every call uses the scratch arena
+        xt, xs, xn, f = _rng_inputs(rng, nt, ns, info, np.float64)
+        jobs.append((i, name, xt, xs, xn, f, np.array([7.5, 0.3]) if name.startswith("Helm") else None))
+
+    def work(job):
+        i, name, xt, xs, xn, f, ctx = job
+        try:
+            for rep in range(5):
+                u = sctl_amd.eval_host(name, xt, xs, xn, f, ctx=ctx)
+                M = sctl_amd.kernel_matrix_host(name, xt[:60].copy(), xs[:90].copy(), xn[:30 * sctl_amd.kernel_info(name)["nd"]].copy() if xn.size else xn, ctx=ctx)
+                results[(i, rep)] = (u, M)
+        except Exception as e:                                      # noqa: BLE001 - reported below
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(j,)) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i, name, xt, xs, xn, f, ctx in jobs:
+        ref = O.eval(name, xt, xs, xn, f, ctx=ctx)
+        refM = O.kernel_matrix(name, xt[:60].copy(), xs[:90].copy(), xn[:30 * O.info(name)["nd"]].copy() if xn.size else xn, ctx=ctx)
+        for rep in range(5):
+            u, M = results[(i, rep)]
+            assert rel_l2(u, ref) <= 1e-12, (i, name, rep, rel_l2(u, ref))
+            assert rel_l2(M, refM) <= 1e-12, (i, name, rep)
+    sctl_amd.api.trim()                                              # releases the cached scratch blocks; the library keeps working
+    i, name, xt, xs, xn, f, ctx = jobs[0]
+    assert rel_l2(sctl_amd.eval_host(name, xt, xs, xn, f, ctx=ctx), O.eval(name, xt, xs, xn, f, ctx=ctx)) <= 1e-12
