@@ -183,7 +183,7 @@ int sctl_amd_eval_plan(int kernel, int real, int64_t Nt, int64_t Ns, int64_t Nt_
                        int* src_splits, int64_t* workgroups, int64_t* workspace_bytes);
 
 /* Which device algorithm sctl_amd_eval_device/_host will use for a problem: 0 = the exact all-pairs kernel
- * (d = x_t - x_s per pair, as generic-kernel.txx:83), 1 = the tile-centred Laplace path (targets Morton-sorted on the
+ * (d = x_t - x_s per pair, as generic-kernel.txx:83), 1 = the tile-centred path of Laplace3D-FxU/-DxU (targets Morton-sorted on the
  * device, far sources through r2 = |x_t'|^2 + |x_s'|^2 - 2 x_t'.x_s', near sources exact).
  * Negative = error code.  Setting SCTL_AMD_CENTERED=0 in the environment forces 0. */
 int sctl_amd_eval_path(int kernel, int real, int64_t Nt, int64_t Ns, int64_t Nt_whole);

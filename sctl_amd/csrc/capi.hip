@@ -19,8 +19,8 @@
 namespace sctl_amd {
 // centered.hip
 template <class R>
-hipError_t eval_laplace_fxu_centered(int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* f, R* v_trg, double scale, int mode, int cus,
-                                     hipStream_t st);
+hipError_t eval_centered(int kernel_id, int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* xn, const R* f, R* v_trg, double scale, int mode,
+                         int cus, hipStream_t st);
 void centered_plan(int64_t Nt, int64_t Ns, int cus, int* T, int* splits, int64_t* chunk);
 namespace {
 
@@ -144,7 +144,7 @@ KerCtx make_ctx(const KernelEntry& k, const void* ctx) {
 bool use_centered(const KernelEntry& k, int real, int64_t Nt, int64_t Ns, int64_t nt_whole = 0) {
   const char* e = std::getenv("SCTL_AMD_CENTERED");   // read per call so that a test can A/B both paths in one process
   const bool enabled = !(e && e[0] == '0'), forced = (e && e[0] == '1');
-  if (!enabled || k.id != SCTL_AMD_LAPLACE3D_FXU || Nt >= (int64_t(1) << 32)) return false;
+  if (!enabled || (k.id != SCTL_AMD_LAPLACE3D_FXU && k.id != SCTL_AMD_LAPLACE3D_DXU) || Nt >= (int64_t(1) << 32)) return false;
   if (forced) return Nt >= 128 && Ns >= 64;
   // What decides is the target DENSITY: with too few targets in the domain the 128 targets of a wave span so much of it
   // that many sources are "near" and the exact kernel wins.  Measured with the near threshold 4 Rt^2 (tools/centred_threshold.py,
@@ -157,8 +157,8 @@ bool use_centered(const KernelEntry& k, int real, int64_t Nt, int64_t Ns, int64_
 }
 
 template <class R>
-int eval_centered(const KernelEntry& k, int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* f, R* v, int mode, hipStream_t st) {
-  HIP_TRY(eval_laplace_fxu_centered<R>(Nt, Ns, xt, xs, f, v, k.scale, mode, cu_count(), st));
+int run_centered(const KernelEntry& k, int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* xn, const R* f, R* v, int mode, hipStream_t st) {
+  HIP_TRY(eval_centered<R>(k.id, Nt, Ns, xt, xs, xn, f, v, k.scale, mode, cu_count(), st));
   g_pairs += Nt * Ns;
   g_flops += Nt * Ns * k.flops;
   return SCTL_AMD_OK;
@@ -171,7 +171,7 @@ int eval_device_t(const KernelEntry& k, int real, int64_t Nt, int64_t Ns, const 
   (void)hipGetLastError();                      // drop a stale error of an earlier, unrelated runtime call on this thread
   const Plan p = make_plan(k, real, Nt, Ns);
   const int mode = mode_for(real, digits);
-  if (use_centered(k, real, Nt, Ns, nt_whole)) return eval_centered<R>(k, Nt, Ns, xt, xs, f, v, mode, st);
+  if (use_centered(k, real, Nt, Ns, nt_whole)) return run_centered<R>(k, Nt, Ns, xt, xs, xn, f, v, mode, st);
   EvalArgs<R> a{};
   a.Nt = Nt; a.Ns = Ns; a.xt = xt; a.xs = xs; a.xn = xn; a.f = f; a.v_trg = v; a.partial = nullptr;
   a.chunk = p.chunk; a.scale = (R)k.scale; a.ctx = make_ctx(k, ctx);

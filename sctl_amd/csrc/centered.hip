@@ -18,12 +18,12 @@ namespace sctl_amd {
   } while (0)
 
 namespace {
-template <class R, int MODE> void launch_centered(const EvalArgs<R>& a, dim3 grid, hipStream_t st) {
-  hipLaunchKernelGGL((laplace_fxu_centered_kernel<R, MODE, 2>), grid, dim3(kWaveBlock), 0, st, a);
+template <class CP, class R, int MODE> void launch_centered(const EvalArgs<R>& a, dim3 grid, hipStream_t st) {
+  hipLaunchKernelGGL((centered_kernel<CP, R, MODE, 2>), grid, dim3(kWaveBlock), 0, st, a);
 }
 }  // namespace
 
-// v_trg[Nt] += scale * sum_s f_s / |x_t - x_s|  (Laplace3D-FxU, fp64), mode = rsqrt refinement (ukernels.hpp)
+// v_trg[Nt] += scale * sum_s (kernel of the policy CP), mode = rsqrt refinement (ukernels.hpp)
 // Launch geometry of the centred kernel: one wave per workgroup, 64*T targets each.  The kernel holds 103 VGPRs, so 16
 // waves are resident per CU; the work per wave varies with its share of near sources (0.5 % .. 34 % at 2^20 uniform
 // points), so the source range is split until there are >= 32 "rounds" of workgroups — measured on 2^20 x 2^20:
@@ -43,9 +43,9 @@ void centered_plan(int64_t Nt, int64_t Ns, int cus, int* T, int* splits, int64_t
   *splits = (int)((Ns + *chunk - 1) / *chunk);
 }
 
-template <class R>
-hipError_t eval_laplace_fxu_centered(int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* f, R* v_trg, double scale_d, int mode, int cus,
-                                     hipStream_t st) {
+template <class CP, class R>
+hipError_t eval_centered_t(int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* xn, const R* f, R* v_trg, double scale_d, int mode, int cus,
+                           hipStream_t st) {
   const R scale = (R)scale_d;
   int T, splits;
   int64_t chunk;
@@ -77,22 +77,29 @@ hipError_t eval_laplace_fxu_centered(int64_t Nt, int64_t Ns, const R* xt, const 
   CENTERED_TRY(hipMemsetAsync(outs, 0, sizeof(R) * Nt, st));
 
   EvalArgs<R> a{};
-  a.Nt = Nt; a.Ns = Ns; a.xt = xts; a.xs = xs; a.xn = nullptr; a.f = f; a.v_trg = outs; a.partial = nullptr;
+  a.Nt = Nt; a.Ns = Ns; a.xt = xts; a.xs = xs; a.xn = xn; a.f = f; a.v_trg = outs; a.partial = nullptr;
   a.chunk = chunk; a.scale = scale;
   a.ctx.v[0] = kNearFactor2;
   if (const char* e = std::getenv("SCTL_AMD_EXPERIMENT_NEAR_FACTOR")) a.ctx.v[0] = std::atof(e);   // timing experiments only
   a.partial = partial;
   const dim3 grid((unsigned)((Nt + (int64_t)kWaveBlock * T - 1) / ((int64_t)kWaveBlock * T)), (unsigned)splits);
-  if (mode == 0) launch_centered<R, 0>(a, grid, st);
-  else if (mode == 1) launch_centered<R, 1>(a, grid, st);
-  else launch_centered<R, (sizeof(R) == 8 ? 2 : 1)>(a, grid, st);
+  if (mode == 0) launch_centered<CP, R, 0>(a, grid, st);
+  else if (mode == 1) launch_centered<CP, R, 1>(a, grid, st);
+  else launch_centered<CP, R, (sizeof(R) == 8 ? 2 : 1)>(a, grid, st);
   CENTERED_TRY(hipGetLastError());
   if (splits > 1)
     hipLaunchKernelGGL((reduce_splits_kernel<R>), dim3(nb), dim3(kBlock), 0, st, outs, (const R*)a.partial, Nt, splits, scale);
   hipLaunchKernelGGL((scatter_add_kernel<R>), dim3(nb), dim3(kBlock), 0, st, (const R*)outs, perm, Nt, 1, v_trg);
   return hipGetLastError();
 }
-template hipError_t eval_laplace_fxu_centered<double>(int64_t, int64_t, const double*, const double*, const double*, double*, double, int, int, hipStream_t);
-template hipError_t eval_laplace_fxu_centered<float>(int64_t, int64_t, const float*, const float*, const float*, float*, double, int, int, hipStream_t);
+// kernel id -> policy
+template <class R>
+hipError_t eval_centered(int kernel_id, int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* xn, const R* f, R* v_trg, double scale, int mode, int cus,
+                         hipStream_t st) {
+  if (kernel_id == Laplace3D_DxU::ID) return eval_centered_t<CenteredDxU<R>, R>(Nt, Ns, xt, xs, xn, f, v_trg, scale, mode, cus, st);
+  return eval_centered_t<CenteredFxU<R>, R>(Nt, Ns, xt, xs, xn, f, v_trg, scale, mode, cus, st);
+}
+template hipError_t eval_centered<double>(int, int64_t, int64_t, const double*, const double*, const double*, const double*, double*, double, int, int, hipStream_t);
+template hipError_t eval_centered<float>(int, int64_t, int64_t, const float*, const float*, const float*, const float*, float*, double, int, int, hipStream_t);
 
 }  // namespace sctl_amd

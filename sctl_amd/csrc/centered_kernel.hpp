@@ -68,18 +68,60 @@ constexpr int kWaveBlock = 64;   // lanes per workgroup of the centred kernel
 constexpr int kWaveTile = 64;    // sources per LDS tile
 constexpr int kNearCap = 128;    // capacity of the per-wave list of pending near sources
 
+// What a kernel needs to run on the centred path (scalar potentials, K1 = 1): besides {x', y', z', |x_s'|^2} a far source
+// carries XW more reals, written by put_extra / put_null and read once per source by load_extra; far_pair is the pair
+// evaluation from the centred quantities.  Near sources go through the kernel's own exact pair (Ker::pack / Ker::pair).
+template <class R> struct CenteredFxU {      // u += f / r
+  using Ker = Laplace3D_FxU;
+  static constexpr int XW = 1;
+  struct Extra { R f; };
+  static __device__ __forceinline__ void put_extra(R* base, int q, const R (&)[3], const R*, const R* f) { base[q] = f[0]; }
+  static __device__ __forceinline__ void put_null(R* base, int q) { base[q] = R(0); }
+  static __device__ __forceinline__ Extra load_extra(const R* base, int s) { return Extra{base[s]}; }
+  template <int MODE> static __device__ __forceinline__ void far_pair(R& acc, const R (&m2x)[3], R tt, const R (&b)[4], const Extra& e, const RsqConst<R>& K) {
+    const R r2 = fma_(m2x[0], b[0], fma_(m2x[1], b[1], fma_(m2x[2], b[2], tt + b[3])));
+    acc = fma_(e.f, rsqrt_masked<MODE, false>(r2, K), acc);
+  }
+};
+template <class R> struct CenteredDxU {      // u += ((x_t - x_s).n f) / r^3, with (x_t - x_s).n f = x_t'.nf - x_s'.nf
+  using Ker = Laplace3D_DxU;
+  static constexpr int XW = 4;               // {-nf/2 (3 components, to be dotted with m2x = -2 x_t'), -(x_s'.nf)}
+  struct Extra { R g[4]; };
+  static __device__ __forceinline__ void put_extra(R* base, int q, const R (&p)[3], const R* n, const R* f) {
+    const R nf[3] = {n[0] * f[0], n[1] * f[0], n[2] * f[0]};
+    Rec4<R>::put((typename Rec4<R>::V*)base + q * Rec4<R>::NW, R(-0.5) * nf[0], R(-0.5) * nf[1], R(-0.5) * nf[2], -(p[0] * nf[0] + p[1] * nf[1] + p[2] * nf[2]));
+  }
+  static __device__ __forceinline__ void put_null(R* base, int q) { Rec4<R>::put((typename Rec4<R>::V*)base + q * Rec4<R>::NW, R(0), R(0), R(0), R(0)); }
+  static __device__ __forceinline__ Extra load_extra(const R* base, int s) {
+    Extra e;
+    Rec4<R>::get((const typename Rec4<R>::V*)base + s * Rec4<R>::NW, e.g);
+    return e;
+  }
+  template <int MODE> static __device__ __forceinline__ void far_pair(R& acc, const R (&m2x)[3], R tt, const R (&b)[4], const Extra& e, const RsqConst<R>& K) {
+    const R r2 = fma_(m2x[0], b[0], fma_(m2x[1], b[1], fma_(m2x[2], b[2], tt + b[3])));
+    const R y = rsqrt_masked<MODE, false>(r2, K);
+    const R dn = fma_(m2x[0], e.g[0], fma_(m2x[1], e.g[1], fma_(m2x[2], e.g[2], e.g[3])));
+    acc = fma_(dn, y * y * y, acc);
+  }
+};
+
 // a.xt: Morton-sorted targets; a.v_trg / a.partial: indexed like a.xt (the caller scatters back).
 // (asking the compiler for 5-6 waves/SIMD instead of the 4 its 118 VGPRs allow costs 1-3 %: measured 464-471 vs 458 ms)
-template <class R, int MODE, int T, int UNR = 4>
-__global__ void __launch_bounds__(kWaveBlock) laplace_fxu_centered_kernel(const EvalArgs<R> a) {
+template <class CP, class R, int MODE, int T, int UNR = 4>
+__global__ void __launch_bounds__(kWaveBlock) centered_kernel(const EvalArgs<R> a) {
   using V = typename Rec4<R>::V;
   constexpr int NW = Rec4<R>::NW;
-  using Ker = Laplace3D_FxU;
-  __shared__ V farB[(kWaveTile + 4) * NW];   // {x', y', z', |x_s'|^2}   (+ padding records)
-  __shared__ R farF[kWaveTile + 4];          // density
-  __shared__ V nearA[(kNearCap + 2) * NW];   // {x, y, z, f}  original coordinates; near sources are collected over
-                                             // several tiles and evaluated in batches, so the exact loop runs rarely
-                                             // and with a long trip count
+  using Ker = typename CP::Ker;
+  static_assert(Ker::K1 == 1 && Ker::K0 == 1, "the centred path is written for scalar densities and potentials");
+  constexpr int ND = Ker::ND;
+  constexpr int NEARW = (Ker::NREC + 3) / 4;                  // Rec4 groups of a near record (the kernel's packed exact record)
+  constexpr int XV = (CP::XW * (int)sizeof(R) + 15) / 16;     // 16-byte words of the extra far record
+  __shared__ V farB[(kWaveTile + 4) * NW];                    // {x', y', z', |x_s'|^2}   (+ padding records)
+  __shared__ V farXv[(kWaveTile + 4) * (XV > 0 ? XV : 1)];    // the policy's extra far reals (density, or the normal terms)
+  __shared__ V nearA[(kNearCap + 2) * NW * NEARW];            // packed exact records; near sources are collected over
+                                                              // several tiles and evaluated in batches, so the exact loop runs
+                                                              // rarely and with a long trip count
+  R* const farX = (R*)farXv;
 
   const int lane = threadIdx.x;
   const int64_t tbase = (int64_t)blockIdx.x * (kWaveBlock * T);
@@ -116,9 +158,9 @@ __global__ void __launch_bounds__(kWaveBlock) laplace_fxu_centered_kernel(const 
   rt2 = uniform_(wave_max(rt2));
   const R near_r2 = R(a.ctx.v[0]) * rt2;   // ctx.v[0] = kNearFactor2; NaN coordinates fail every comparison => "near" => exact path
 
-  R acc[T];
+  R acc[T][1];
 #pragma unroll
-  for (int j = 0; j < T; j++) acc[j] = 0;
+  for (int j = 0; j < T; j++) acc[j][0] = 0;
 
   const int64_t s_begin = (int64_t)blockIdx.y * a.chunk;
   const int64_t s_end = (s_begin + a.chunk < a.Ns) ? s_begin + a.chunk : a.Ns;
@@ -126,23 +168,34 @@ __global__ void __launch_bounds__(kWaveBlock) laplace_fxu_centered_kernel(const 
   const int ntile = (int)((len + kWaveTile - 1) / kWaveTile);
 
   // software pipeline: the next tile's source is loaded into registers while the current tile is evaluated
-  R x[3] = {0, 0, 0}, f = 0;
+  R x[3] = {0, 0, 0}, nrm[3] = {0, 0, 0}, f[1] = {0};
   auto load_source = [&](int it) {
     const int64_t s = s_begin + (int64_t)it * kWaveTile + lane;
     if (s < s_end) {
 #pragma unroll
       for (int k = 0; k < 3; k++) x[k] = a.xs[s * 3 + k];
-      f = a.f[s];
+#pragma unroll
+      for (int k = 0; k < ND; k++) nrm[k] = a.xn[s * ND + k];
+      f[0] = a.f[s];
     }
   };
   if (ntile > 0) load_source(0);
 
   // ---- near sources: the reference-exact pair (d = x_t - x_s, masked at r = 0), evaluated in batches -----------
   const R far_off = R(1.0e3) * (R(1) + sqrt_(rt2));
+  auto put_near = [&](int q, const R (&xq)[3], const R (&nq)[3], const R (&fq)[1]) {
+    R rec[4 * NEARW] = {};
+    Ker::template pack<R>(rec, xq, nq, fq);
+#pragma unroll
+    for (int g = 0; g < NEARW; g++) Rec4<R>::put(nearA + (q * NEARW + g) * NW, rec[4 * g], rec[4 * g + 1], rec[4 * g + 2], rec[4 * g + 3]);
+  };
   int nn = 0;   // pending near sources in nearA (wave-uniform)
   auto flush_near = [&]() {
     if (nn & 1) {   // pad to an even count with a null source
-      if (lane == 0) Rec4<R>::put(nearA + nn * NW, c[0] + far_off, c[1], c[2], R(0));
+      if (lane == 0) {
+        const R xq[3] = {c[0] + far_off, c[1], c[2]}, nq[3] = {0, 0, 0}, fq[1] = {0};
+        put_near(nn, xq, nq, fq);
+      }
       __syncthreads();
     }
     R xo[T][3];   // the original target coordinates are needed only here: reloaded (L2 hit) rather than kept in 12 VGPRs
@@ -156,12 +209,17 @@ __global__ void __launch_bounds__(kWaveBlock) laplace_fxu_centered_kernel(const 
     for (int s = 0; s < nn; s += 2) {
 #pragma unroll
       for (int u = 0; u < 2; u++) {
-        R q[4];
-        Rec4<R>::get(nearA + (s + u) * NW, q);
+        R q[4 * NEARW];
+#pragma unroll
+        for (int g = 0; g < NEARW; g++) {
+          R w[4];
+          Rec4<R>::get(nearA + ((s + u) * NEARW + g) * NW, w);
+          q[4 * g] = w[0]; q[4 * g + 1] = w[1]; q[4 * g + 2] = w[2]; q[4 * g + 3] = w[3];
+        }
 #pragma unroll
         for (int j = 0; j < T; j++) {
           const R d[3] = {xo[j][0] - q[0], xo[j][1] - q[1], xo[j][2] - q[2]};
-          acc[j] = fma_(q[3], rsqrt_masked<MODE, true>(len2(d), K.rsq), acc[j]);
+          Ker::template pair<R, MODE, true>(acc[j], d, q, a.ctx, K);
         }
       }
     }
@@ -187,17 +245,16 @@ __global__ void __launch_bounds__(kWaveBlock) laplace_fxu_centered_kernel(const 
     if (is_far) {
       const int q = __popcll(bf & below);
       Rec4<R>::put(farB + q * NW, p[0], p[1], p[2], ss);
-      farF[q] = f;
+      CP::put_extra(farX, q, p, nrm, f);
     } else if (is_near) {
-      const int q = nn + __popcll(bn & below);
-      Rec4<R>::put(nearA + q * NW, x[0], x[1], x[2], f);
+      put_near(nn + __popcll(bn & below), x, nrm, f);
     }
     nn += nnear;
     // pad the far list to a multiple of UNR with null sources (zero density at ~1e3 cluster radii): they contribute
     // exactly 0 and remove the low-ILP remainder loop
     if (lane < UNR - 1) {
       const int q = nfar + lane;
-      if (q < ((nfar + UNR - 1) & ~(UNR - 1))) { Rec4<R>::put(farB + q * NW, far_off, R(0), R(0), far_off * far_off); farF[q] = R(0); }
+      if (q < ((nfar + UNR - 1) & ~(UNR - 1))) { Rec4<R>::put(farB + q * NW, far_off, R(0), R(0), far_off * far_off); CP::put_null(farX, q); }
     }
     if (it + 1 < ntile) load_source(it + 1);
     __syncthreads();
@@ -211,16 +268,13 @@ __global__ void __launch_bounds__(kWaveBlock) laplace_fxu_centered_kernel(const 
       for (int u = 0; u < UNR; u++) {
         R b[4];
         Rec4<R>::get(farB + (s + u) * NW, b);
-        const R fs = farF[s + u];
+        const typename CP::Extra e = CP::load_extra(farX, s + u);
 #pragma unroll
-        for (int j = 0; j < T; j++) {
-          const R r2 = fma_(m2x[j][0], b[0], fma_(m2x[j][1], b[1], fma_(m2x[j][2], b[2], tt[j] + b[3])));
-          tacc[j] = fma_(fs, rsqrt_masked<MODE, false>(r2, K.rsq), tacc[j]);
-        }
+        for (int j = 0; j < T; j++) CP::template far_pair<MODE>(tacc[j], m2x[j], tt[j], b, e, K.rsq);
       }
     }
 #pragma unroll
-    for (int j = 0; j < T; j++) acc[j] += tacc[j];
+    for (int j = 0; j < T; j++) acc[j][0] += tacc[j];
   }
   __syncthreads();
   flush_near();
@@ -229,8 +283,8 @@ __global__ void __launch_bounds__(kWaveBlock) laplace_fxu_centered_kernel(const 
   for (int j = 0; j < T; j++) {
     const int64_t t = tbase + j * kWaveBlock + lane;
     if (t < a.Nt) {
-      if (gridDim.y == 1) a.v_trg[t] += acc[j] * a.scale;
-      else a.partial[(int64_t)blockIdx.y * a.Nt + t] = acc[j];
+      if (gridDim.y == 1) a.v_trg[t] += acc[j][0] * a.scale;
+      else a.partial[(int64_t)blockIdx.y * a.Nt + t] = acc[j][0];
     }
   }
 }

@@ -87,7 +87,8 @@ def test_launch_planner():
         head = sctl_amd.plan("Laplace3D-FxU", 0, 1 << 20, 1 << 20)
         assert head["path"] == "tile-centred" and head["src_splits"] == 16 and head["workgroups"] == 8192 * 16
         assert sctl_amd.plan("Laplace3D-FxU", 1, 1 << 20, 1 << 20)["path"] == "tile-centred"
-        assert sctl_amd.plan("Laplace3D-DxU", 0, 1 << 20, 1 << 20)["path"] == "exact"         # only the single layer has a centred form
+        assert sctl_amd.plan("Laplace3D-DxU", 0, 1 << 20, 1 << 20)["path"] == "tile-centred"  # scalar Laplace kernels have a centred form
+        assert sctl_amd.plan("Laplace3D-FxdU", 0, 1 << 20, 1 << 20)["path"] == "exact"        # the gradient needs x_t - x_s anyway
 
 
 def test_product_tree_never_touches_the_oracle():

@@ -37,25 +37,28 @@ def _clouds(kind, rng):
 
 
 @pytest.mark.parametrize("kind", ["uniform", "clustered", "surface", "identical_targets", "offset"])
-def test_centred_path_matches_oracle_and_exact_kernel(O, kind):
+@pytest.mark.parametrize("name", ["Laplace3D-FxU", "Laplace3D-DxU"])
+def test_centred_path_matches_oracle_and_exact_kernel(O, name, kind):
     import torch
     rng = np.random.default_rng(123)
     xt, xs = _clouds(kind, rng)
     xt, xs = np.ascontiguousarray(xt.ravel()), np.ascontiguousarray(xs.ravel())
     f = rng.random(NS) - 0.5
-    assert sctl_amd.plan("Laplace3D-FxU", 0, NT, NS)["path"] == "tile-centred"
-    d = [torch.from_numpy(a).cuda() for a in (xt, xs, f)]
-    u = sctl_amd.eval_device("Laplace3D-FxU", d[0], d[1], None, d[2]).cpu().numpy()
+    xn = (rng.random(NS * 3) - 0.5) if name.endswith("DxU") else None
+    assert sctl_amd.plan(name, 0, NT, NS)["path"] == "tile-centred"
+    d = [None if a is None else torch.from_numpy(a).cuda() for a in (xt, xs, xn, f)]
+    u = sctl_amd.eval_device(name, *d).cpu().numpy()
     assert np.all(np.isfinite(u))
     os.environ["SCTL_AMD_CENTERED"] = "0"
     try:
-        assert sctl_amd.plan("Laplace3D-FxU", 0, NT, NS)["path"] == "exact"
-        u_exact = sctl_amd.eval_device("Laplace3D-FxU", d[0], d[1], None, d[2]).cpu().numpy()
+        assert sctl_amd.plan(name, 0, NT, NS)["path"] == "exact"
+        u_exact = sctl_amd.eval_device(name, *d).cpu().numpy()
     finally:
         del os.environ["SCTL_AMD_CENTERED"]
-    assert rel_l2(u, u_exact) <= 2e-14, rel_l2(u, u_exact)
+    # the double layer sums signed terms of size 1/r^2: where they nearly cancel the two summation orders differ more
+    assert rel_l2(u, u_exact) <= (2e-14 if name.endswith("FxU") else 2e-13), rel_l2(u, u_exact)
     sel = rng.choice(NT, 300, replace=False)
-    ref = O.eval("Laplace3D-FxU", xt.reshape(NT, 3)[sel].ravel().copy(), xs, None, f)
+    ref = O.eval(name, xt.reshape(NT, 3)[sel].ravel().copy(), xs, xn, f)
     assert rel_l2(u[sel], ref) <= 1e-12, rel_l2(u[sel], ref)
 
 
@@ -74,22 +77,24 @@ def test_centred_path_accumulates_and_honours_digits(O):
         assert rel_l2(v[sel], ref) <= tol, (digits, rel_l2(v[sel], ref))
 
 
-def test_centred_path_fp32(O):
+@pytest.mark.parametrize("name", ["Laplace3D-FxU", "Laplace3D-DxU"])
+def test_centred_path_fp32(O, name):
     """fp32 through the tile-centred path against the fp64 oracle (tolerance of SURVEY.md §8d) and the exact fp32 kernel."""
     import torch
     rng = np.random.default_rng(9)
     n = 1 << 18
     xt, xs, f = rng.random(n * 3).astype(np.float32), rng.random(n * 3).astype(np.float32), (rng.random(n) - 0.5).astype(np.float32)
-    assert sctl_amd.plan("Laplace3D-FxU", 1, n, n)["path"] == "tile-centred"
-    d = [torch.from_numpy(a).cuda() for a in (xt, xs, f)]
-    u = sctl_amd.eval_device("Laplace3D-FxU", d[0], d[1], None, d[2]).cpu().numpy()
+    xn = (rng.random(n * 3) - 0.5).astype(np.float32) if name.endswith("DxU") else None
+    assert sctl_amd.plan(name, 1, n, n)["path"] == "tile-centred"
+    d = [None if a is None else torch.from_numpy(a).cuda() for a in (xt, xs, xn, f)]
+    u = sctl_amd.eval_device(name, *d).cpu().numpy()
     os.environ["SCTL_AMD_CENTERED"] = "0"
     try:
-        u_exact = sctl_amd.eval_device("Laplace3D-FxU", d[0], d[1], None, d[2]).cpu().numpy()
+        u_exact = sctl_amd.eval_device(name, *d).cpu().numpy()
     finally:
         del os.environ["SCTL_AMD_CENTERED"]
     sel = rng.choice(n, 300, replace=False)
-    ref = O.eval("Laplace3D-FxU", xt.reshape(n, 3)[sel].astype(np.float64).ravel().copy(), xs.astype(np.float64), None, f.astype(np.float64))
+    ref = O.eval(name, xt.reshape(n, 3)[sel].astype(np.float64).ravel().copy(), xs.astype(np.float64), None if xn is None else xn.astype(np.float64), f.astype(np.float64))
     e_c, e_x = rel_l2(u[sel], ref), rel_l2(u_exact[sel], ref)
     assert e_c <= 1e-4 and e_c <= 3 * e_x + 1e-6, (e_c, e_x)
 
