@@ -138,6 +138,13 @@ int sctl_amd_op_create(int kernel, int real, const int* devices, int n_devices, 
 /* HOST arrays, copied to the devices before returning; either may be called again at any time (new coordinates). */
 int sctl_amd_op_set_targets(sctl_amd_op* op, int64_t Nt, const void* r_trg);
 int sctl_amd_op_set_sources(sctl_amd_op* op, int64_t Ns, const void* r_src, const void* n_src);
+/* The far-field pre/post steps of BoundaryIntegralOp::ComputeFarField, kept on the device (both optional, HOST arrays, NULL clears):
+ * weights[Ns]: every evaluation multiplies the uploaded density by the quadrature weights, f[s][k] *= w[s] (boundary_integral.txx:
+ * 1040-1052); call after sctl_amd_op_set_sources (new sources drop the weights).  n_trg[Nt*3]: the TrgDim = 3*m output of the kernel is
+ * contracted with the target normal, u[t][k] = sum_l v[t][k][l] n_trg[t][l] (:1060-1071), and sctl_amd_op_eval's v_trg then holds
+ * Nt*TrgDim/3 values; call after sctl_amd_op_set_targets (new targets drop the normals). */
+int sctl_amd_op_set_source_weights(sctl_amd_op* op, const void* weights);
+int sctl_amd_op_set_target_normals(sctl_amd_op* op, const void* n_trg);
 /* v_src[Ns*SrcDim] and v_trg[Nt*TrgDim] are HOST arrays.  accumulate != 0: v_trg += result (GenericKernel::Eval,
  * generic-kernel.txx:184); accumulate == 0: v_trg = result (ParticleFMM::EvalDirect, fmm-wrapper.txx:501-502). */
 int sctl_amd_op_eval(sctl_amd_op* op, const void* v_src, void* v_trg, int accumulate, int digits, const void* ctx, int ctx_bytes);

@@ -4,6 +4,7 @@
 //     F_far = density at the far-field quadrature nodes x quadrature weights      boundary_integral.txx:1021-1053
 //     fmm.SetSrcDensity("Src", F_far); fmm.Eval(U, "Trg")                          boundary_integral.txx:1054-1073
 //     optional dot product of the K1/3 x 3 output with the target normals          boundary_integral.txx:1060-1071
+// (here one sctl_amd_op_eval: the weights multiply and the normal contraction run on the device)
 // with the wiring of the constructor (:500-509), SetupBasic (:690-766) and SetupFar (:744-782).
 //
 // Same names and argument meaning as the reference for everything on that leg: ElementListBase (Size, GetNodeCoord,
@@ -80,17 +81,13 @@ template <class Real, class Kernel> class BoundaryIntegralOp {
 
   // boundary_integral.txx:500-509
   explicit BoundaryIntegralOp(const Kernel& ker, bool trg_normal_dot_prod = false, const Comm& comm = Comm::Self())
-      : tol_(1e-10), ker_(ker), trg_normal_dot_prod_(trg_normal_dot_prod), comm_(comm), fmm(comm) {
+      : tol_(1e-10), ker_(ker), trg_normal_dot_prod_(trg_normal_dot_prod), comm_(comm) {
     SCTL_AMD_ASSERT(!trg_normal_dot_prod_ || (KDIM1 % COORD_DIM == 0));
     ClearSetup();
-    fmm.SetKernels(ker, ker, ker);
-    fmm.AddSrc("Src", ker, ker);
-    fmm.AddTrg("Trg", ker, ker);
-    fmm.SetKernelS2T("Src", "Trg", ker);
-    fmm.SetAccuracy((Integer)(std::log(tol_) / std::log(0.1)) + 1);
   }
   ~BoundaryIntegralOp() {
     ReleaseNearOp();
+    ReleaseFarOp();
     for (auto& it : elem_lst_map) delete it.second;
   }
 
@@ -100,7 +97,6 @@ template <class Real, class Kernel> class BoundaryIntegralOp {
     setup_self_flag = false;
     setup_near_flag = false;
     tol_ = tol;
-    fmm.SetAccuracy((Integer)(std::log(tol_) / std::log(0.1)) + 1);
   }
 
   template <class ElemLstType> void AddElemList(const ElemLstType& elem_lst, const std::string& name = std::to_string(typeid(ElemLstType).hash_code())) {
@@ -169,7 +165,7 @@ template <class Real, class Kernel> class BoundaryIntegralOp {
     const Long Nsrc = X_far.Dim() / COORD_DIM;
     const Long Ntrg = Xtrg.Dim() / COORD_DIM;
     SCTL_AMD_ASSERT(F.Dim() == Dim(0));
-    {  // F_far = (density at the far-field nodes) * wts_far
+    {  // F_far = density at the far-field nodes; the quadrature weights are applied on the device (:1040-1052)
       if (F_far.Dim() != Nsrc * KDIM0) F_far.ReInit(Nsrc * KDIM0);
       const Long Nlst = (Long)elem_lst_name.size();
       for (Long i = 0; i < Nlst; i++) {
@@ -183,30 +179,21 @@ template <class Real, class Kernel> class BoundaryIntegralOp {
         elem_lst_map.at(elem_lst_name[i])->GetFarFieldDensity(F_far_, F_);
         if (F_far_.Dim()) {
           SCTL_AMD_ASSERT(F_far_.begin() == F_far.begin() + offset0_far * KDIM0);   // filled in place, not reallocated
-          for (Long j = offset0_far; j < offset1_far; j++)
-            for (Long k = 0; k < KDIM0; k++) F_far[j * KDIM0 + k] *= wts_far[j];
-        } else {
+        } else {                                                                     // "same nodes": the density as it is
           SCTL_AMD_ASSERT(offset1_far - offset0_far == offset1 - offset0);
           for (Long j = offset0_far; j < offset1_far; j++)
-            for (Long k = 0; k < KDIM0; k++) F_far[j * KDIM0 + k] = F_[(j - offset0_far) * KDIM0 + k] * wts_far[j];
+            for (Long k = 0; k < KDIM0; k++) F_far[j * KDIM0 + k] = F_[(j - offset0_far) * KDIM0 + k];
         }
       }
     }
-    fmm.SetSrcDensity("Src", F_far);
-
     const Integer KDIM1_ = (trg_normal_dot_prod_ ? KDIM1 / COORD_DIM : KDIM1);
     if (U.Dim() != Ntrg * KDIM1_) U.ReInit(Ntrg * KDIM1_);
     U.SetZero();
-    if (trg_normal_dot_prod_) {
-      Vector<Real> U_(Ntrg * KDIM1);
-      U_.SetZero();
-      fmm.Eval(U_, "Trg");
-      for (Long i = 0; i < Ntrg; i++)
-        for (Long k = 0; k < KDIM1_; k++)
-          for (Long l = 0; l < COORD_DIM; l++) U[i * KDIM1_ + k] += U_[(i * KDIM1_ + k) * COORD_DIM + l] * Xn_trg[i * COORD_DIM + l];
-    } else {
-      fmm.Eval(U, "Trg");
-    }
+    if (!Ntrg || !Nsrc) return;
+    // The weights and the target normals live on the devices with the coordinates (sctl_amd_op_set_source_weights /
+    // _target_normals, uploaded by SetupFar): one evaluation moves the unweighted density down and the contracted potential up.
+    const int rc = sctl_amd_op_eval(far_op, F_far.begin(), U.begin(), /*accumulate*/ 0, fmm_digits(), ker_.GetCtxPtr(), (int)Kernel::CTX_BYTES);
+    CheckStatus(rc, "sctl_amd_op_eval");
   }
 
   // boundary_integral.txx:608-614
@@ -334,8 +321,18 @@ template <class Real, class Kernel> class BoundaryIntegralOp {
     concat(elem_nds_cnt_far, cnt_far_);
     SCTL_AMD_ASSERT(elem_nds_cnt_far.Dim() == elem_nds_cnt.Dim());
     scan(elem_nds_cnt_far, elem_nds_dsp_far);
-    fmm.SetSrcCoord("Src", X_far, Xn_far);
-    fmm.SetTrgCoord("Trg", Xtrg);
+    // The reference hands these to its ParticleFMM member (:776-779); here they go straight to a device-resident operator,
+    // together with the quadrature weights and the target normals, which ComputeFarField then never touches on the host.
+    ReleaseFarOp();
+    const Long Nsrc = X_far.Dim() / COORD_DIM, Ntrg = Xtrg.Dim() / COORD_DIM;
+    if (Nsrc && Ntrg) {
+      const std::vector<int>& devs = DeviceSet::Get();
+      CheckStatus(sctl_amd_op_create(ker_.DeviceKernelId(), RealTag<Real>::value, devs.data(), (int)devs.size(), &far_op), "sctl_amd_op_create");
+      CheckStatus(sctl_amd_op_set_targets(far_op, Ntrg, Xtrg.begin()), "sctl_amd_op_set_targets");
+      CheckStatus(sctl_amd_op_set_sources(far_op, Nsrc, X_far.begin(), Kernel::NormalDim() ? Xn_far.begin() : nullptr), "sctl_amd_op_set_sources");
+      CheckStatus(sctl_amd_op_set_source_weights(far_op, wts_far.begin()), "sctl_amd_op_set_source_weights");
+      if (trg_normal_dot_prod_) CheckStatus(sctl_amd_op_set_target_normals(far_op, Xn_trg.begin()), "sctl_amd_op_set_target_normals");
+    }
     setup_far_flag = true;
   }
 
@@ -533,6 +530,11 @@ template <class Real, class Kernel> class BoundaryIntegralOp {
     setup_near_flag = true;
   }
 
+  int fmm_digits() const { return (int)(std::log(tol_) / std::log(0.1)) + 1; }   // tolerance -> digits, as :520
+  void ReleaseFarOp() const {
+    if (far_op) sctl_amd_op_destroy(far_op);
+    far_op = nullptr;
+  }
   void ReleaseNearOp() const {
     if (near_op) sctl_amd_near_destroy(near_op);
     near_op = nullptr;
@@ -561,7 +563,7 @@ template <class Real, class Kernel> class BoundaryIntegralOp {
   mutable Vector<Long> elem_lst_cnt, elem_lst_dsp;          // elements per element list
   mutable Vector<Long> elem_nds_cnt, elem_nds_dsp;          // surface nodes per element
   mutable Vector<Real> Xsurf, Xn_surf, Xtrg, Xn_trg;
-  mutable ParticleFMM<Real, COORD_DIM> fmm;
+  mutable sctl_amd_op* far_op = nullptr;                    // far field: coordinates, weights and target normals resident on the GPUs
   mutable Vector<Long> elem_nds_cnt_far, elem_nds_dsp_far;  // far-field nodes per element
   mutable Vector<Real> X_far, Xn_far, wts_far, dist_far, F_far;
   // near field: the arrays of boundary_integral.hpp:381-396, and their device-resident form

@@ -24,7 +24,7 @@ SYMBOLS = ["sctl_amd_version", "sctl_amd_last_error", "sctl_amd_device_count", "
            "sctl_amd_kernel_info", "sctl_amd_flops_per_pair", "sctl_amd_eval_device", "sctl_amd_eval_device_slab", "sctl_amd_eval_host", "sctl_amd_eval_host_multi",
            "sctl_amd_kernel_matrix_device", "sctl_amd_kernel_matrix_host", "sctl_amd_kernel_matrix_batch_host", "sctl_amd_counters", "sctl_amd_reset_counters", "sctl_amd_trim",
            "sctl_amd_eval_plan", "sctl_amd_eval_path", "sctl_amd_op_create", "sctl_amd_op_set_targets",
-           "sctl_amd_op_set_sources", "sctl_amd_op_eval", "sctl_amd_op_destroy", "sctl_amd_near_create", "sctl_amd_near_apply_host",
+           "sctl_amd_op_set_sources", "sctl_amd_op_set_source_weights", "sctl_amd_op_set_target_normals", "sctl_amd_op_eval", "sctl_amd_op_destroy", "sctl_amd_near_create", "sctl_amd_near_apply_host",
            "sctl_amd_near_apply_device", "sctl_amd_near_info", "sctl_amd_near_destroy"]
 
 
@@ -96,6 +96,8 @@ def lib():
     L.sctl_amd_op_create.argtypes = [ci, ci, C.POINTER(C.c_int), ci, C.POINTER(vp)]
     L.sctl_amd_op_set_targets.argtypes = [vp, i64, vp]
     L.sctl_amd_op_set_sources.argtypes = [vp, i64, vp, vp]
+    L.sctl_amd_op_set_source_weights.argtypes = [vp, vp]
+    L.sctl_amd_op_set_target_normals.argtypes = [vp, vp]
     L.sctl_amd_op_eval.argtypes = [vp, vp, vp, ci, ci, vp, ci]
     L.sctl_amd_op_destroy.argtypes = [vp]
     L.sctl_amd_op_destroy.restype = None
@@ -348,6 +350,7 @@ class DirectOp:
 
     def set_targets(self, r_trg):
         self.Nt = r_trg.size // 3
+        self._dot = False
         _check(lib().sctl_amd_op_set_targets(self._h, self.Nt, _np_ptr(r_trg, self.dtype, self.Nt * 3, "r_trg")), "op_set_targets")
 
     def set_sources(self, r_src, n_src=None):
@@ -355,12 +358,23 @@ class DirectOp:
         _check(lib().sctl_amd_op_set_sources(self._h, self.Ns, _np_ptr(r_src, self.dtype, self.Ns * 3, "r_src"),
                                              _np_ptr(n_src, self.dtype, self.Ns * self.info["nd"], "n_src")), "op_set_sources")
 
+    def set_source_weights(self, weights):
+        """Quadrature weights applied to every density on the device (None clears); after set_sources."""
+        self._weights = weights is not None
+        _check(lib().sctl_amd_op_set_source_weights(self._h, None if weights is None else _np_ptr(weights, self.dtype, self.Ns, "weights")), "op_set_source_weights")
+
+    def set_target_normals(self, n_trg):
+        """The kernel's output is contracted with these normals on the device, TrgDim -> TrgDim/3 (None clears); after set_targets."""
+        _check(lib().sctl_amd_op_set_target_normals(self._h, None if n_trg is None else _np_ptr(n_trg, self.dtype, self.Nt * 3, "n_trg")), "op_set_target_normals")
+        self._dot = n_trg is not None
+
     def eval(self, v_src, v_trg=None, accumulate=False, digits=-1):
-        if v_trg is None or v_trg.size != self.Nt * self.info["k1"]:
-            v_trg = np.zeros(self.Nt * self.info["k1"], dtype=self.dtype)
+        k1 = self.info["k1"] // 3 if getattr(self, "_dot", False) else self.info["k1"]
+        if v_trg is None or v_trg.size != self.Nt * k1:
+            v_trg = np.zeros(self.Nt * k1, dtype=self.dtype)
         keep, cp, cb = _ctx_blob(self.info, self.ctx)
         _check(lib().sctl_amd_op_eval(self._h, _np_ptr(v_src, self.dtype, self.Ns * self.info["k0"], "v_src"),
-                                      _np_ptr(v_trg, self.dtype, self.Nt * self.info["k1"], "v_trg"), 1 if accumulate else 0, digits, cp, cb), "op_eval")
+                                      _np_ptr(v_trg, self.dtype, self.Nt * k1, "v_trg"), 1 if accumulate else 0, digits, cp, cb), "op_eval")
         return v_trg
 
     def close(self):

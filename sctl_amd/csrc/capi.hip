@@ -352,6 +352,8 @@ struct OpDevice {
   int64_t t0 = 0, t1 = 0;                 // target slab of this device
   void *xt = nullptr, *xs = nullptr, *xn = nullptr, *f = nullptr, *v = nullptr;
   size_t cap_xt = 0, cap_xs = 0, cap_xn = 0, cap_f = 0, cap_v = 0;
+  void *w = nullptr, *nt = nullptr, *u = nullptr;   // source weights, target normals (this slab), contracted potential
+  size_t cap_w = 0, cap_nt = 0, cap_u = 0;
   PinnedBuf stage;                        // pinned staging for uploads and for the slab of the potential
 };
 
@@ -373,6 +375,7 @@ struct sctl_amd_op {
   // several devices: the slabs are cut from the Morton order of the targets, so that a device's targets keep the
   // density of the whole set (what the tile-centred path needs); perm[i] = caller's index of sorted target i
   std::vector<int64_t> perm;
+  bool have_weights = false, have_trg_normals = false;   // far-field pre/post steps on the device (sctl_amd_op_set_source_weights / _target_normals)
 };
 
 namespace sctl_amd {
@@ -657,7 +660,7 @@ void sctl_amd_op_destroy(sctl_amd_op* op) {
   for (OpDevice& d : op->devs) {
     if (d.device < 0 || d.device >= avail || !d.st) continue;   // never initialised (create failed on this entry)
     if (hipSetDevice(d.device) != hipSuccess) { (void)hipGetLastError(); continue; }
-    for (void* p : {d.xt, d.xs, d.xn, d.f, d.v})
+    for (void* p : {d.xt, d.xs, d.xn, d.f, d.v, d.w, d.nt, d.u})
       if (p) (void)hipFree(p);
     if (d.st) { workspace_forget(d.st); (void)hipStreamDestroy(d.st); }
   }
@@ -669,6 +672,7 @@ int sctl_amd_op_set_targets(sctl_amd_op* op, int64_t Nt, const void* r_trg) {
   const size_t rs = (op->real == SCTL_AMD_F64) ? 8 : 4;
   const int G = (int)op->devs.size();
   op->Nt = Nt;
+  op->have_trg_normals = false;   // normals belong to a target set: set them again after new targets
   int g = 0;
   for (OpDevice& d : op->devs) { d.t0 = Nt * g / G; d.t1 = Nt * (g + 1) / G; g++; }   // fmm-wrapper.txx:507
   // several devices: slabs of the Morton-ordered targets (coordinates gathered into sorted order once, here)
@@ -697,6 +701,7 @@ int sctl_amd_op_set_sources(sctl_amd_op* op, int64_t Ns, const void* r_src, cons
   if (Ns > 0 && op->k->nd > 0 && !n_src) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, std::string(op->k->name) + " needs source normals (n_src is null)");
   const size_t rs = (op->real == SCTL_AMD_F64) ? 8 : 4;
   op->Ns = Ns;
+  op->have_weights = false;       // weights belong to a source set
   return op_for_each_device(op, [&](OpDevice& d) -> int {
     HIP_TRY(hipSetDevice(d.device));
     HIP_TRY(grow(&d.xs, &d.cap_xs, (size_t)Ns * 3 * rs));
@@ -707,6 +712,47 @@ int sctl_amd_op_set_sources(sctl_amd_op* op, int64_t Ns, const void* r_src, cons
     HIP_TRY(hipStreamSynchronize(d.st));
     return SCTL_AMD_OK;
   });
+}
+
+int sctl_amd_op_set_source_weights(sctl_amd_op* op, const void* wts) {
+  if (!op) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "null handle");
+  if (!wts) { op->have_weights = false; return SCTL_AMD_OK; }
+  const size_t rs = (op->real == SCTL_AMD_F64) ? 8 : 4;
+  const int64_t Ns = op->Ns;
+  const int rc = op_for_each_device(op, [&](OpDevice& d) -> int {
+    HIP_TRY(hipSetDevice(d.device));
+    HIP_TRY(grow(&d.w, &d.cap_w, (size_t)Ns * rs));
+    HIP_TRY(d.stage.reserve(pad256((size_t)Ns * rs)));
+    HIP_TRY(upload(d.w, wts, (size_t)Ns * rs, d.stage, d.st));
+    HIP_TRY(hipStreamSynchronize(d.st));
+    return SCTL_AMD_OK;
+  });
+  op->have_weights = (rc == SCTL_AMD_OK);
+  return rc;
+}
+
+int sctl_amd_op_set_target_normals(sctl_amd_op* op, const void* n_trg) {
+  if (!op) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "null handle");
+  if (!n_trg) { op->have_trg_normals = false; return SCTL_AMD_OK; }
+  if (op->k->k1 % 3 != 0) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, std::string(op->k->name) + ": TrgDim is not a multiple of 3, nothing to contract with a normal");
+  const size_t rs = (op->real == SCTL_AMD_F64) ? 8 : 4;
+  std::vector<char> sorted;   // several devices: the targets live in Morton order
+  if (!op->perm.empty()) {
+    sorted.resize((size_t)op->Nt * 3 * rs);
+    for (int64_t i = 0; i < op->Nt; i++) std::memcpy(&sorted[(size_t)i * 3 * rs], (const char*)n_trg + (size_t)op->perm[(size_t)i] * 3 * rs, 3 * rs);
+  }
+  const char* src = sorted.empty() ? (const char*)n_trg : sorted.data();
+  const int rc = op_for_each_device(op, [&](OpDevice& d) -> int {
+    const size_t bytes = (size_t)(d.t1 - d.t0) * 3 * rs;
+    HIP_TRY(hipSetDevice(d.device));
+    HIP_TRY(grow(&d.nt, &d.cap_nt, bytes));
+    HIP_TRY(d.stage.reserve(pad256(bytes)));
+    HIP_TRY(upload(d.nt, src + (size_t)d.t0 * 3 * rs, bytes, d.stage, d.st));
+    HIP_TRY(hipStreamSynchronize(d.st));
+    return SCTL_AMD_OK;
+  });
+  op->have_trg_normals = (rc == SCTL_AMD_OK);
+  return rc;
 }
 
 int sctl_amd_op_eval(sctl_amd_op* op, const void* v_src, void* v_trg, int accumulate, int digits, const void* ctx, int ctx_bytes) {
@@ -726,6 +772,12 @@ int sctl_amd_op_eval(sctl_amd_op* op, const void* v_src, void* v_trg, int accumu
     HIP_TRY(grow(&d.v, &d.cap_v, vbytes));
     HIP_TRY(d.stage.reserve(pad256((size_t)Ns * k.k0 * rs) + pad256(vbytes)));
     HIP_TRY(upload(d.f, v_src, (size_t)Ns * k.k0 * rs, d.stage, d.st));
+    if (op->have_weights) {   // density x quadrature weights (boundary_integral.txx:1040-1052)
+      const unsigned nb = (unsigned)((Ns * k.k0 + kBlock - 1) / kBlock);
+      if (op->real == SCTL_AMD_F64) hipLaunchKernelGGL((scale_density_kernel<double>), dim3(nb), dim3(kBlock), 0, d.st, (double*)d.f, (const double*)d.w, Ns, k.k0);
+      else hipLaunchKernelGGL((scale_density_kernel<float>), dim3(nb), dim3(kBlock), 0, d.st, (float*)d.f, (const float*)d.w, Ns, k.k0);
+      HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipMemsetAsync(d.v, 0, vbytes, d.st));
     int rc;
     if (op->real == SCTL_AMD_F64)
@@ -735,13 +787,24 @@ int sctl_amd_op_eval(sctl_amd_op* op, const void* v_src, void* v_trg, int accumu
       rc = eval_device_t<float>(k, op->real, nt, Ns, (const float*)d.xt, (const float*)d.xs, (const float*)d.xn, (const float*)d.f, (float*)d.v, digits,
                                 ctx, d.st, op->perm.empty() ? 0 : op->Nt);
     if (rc) return rc;
-    char* dst = (char*)v_trg + (size_t)d.t0 * k.k1 * rs;
-    const char* out = d.stage.take(vbytes);
-    HIP_TRY(hipMemcpyAsync((void*)out, d.v, vbytes, hipMemcpyDeviceToHost, d.st));
+    int k1 = k.k1;            // components per target that go back to the host
+    const void* result = d.v;
+    if (op->have_trg_normals) {   // contract the last index with the target normal (boundary_integral.txx:1060-1071): 3x less D2H
+      k1 = k.k1 / 3;
+      HIP_TRY(grow(&d.u, &d.cap_u, (size_t)nt * k1 * rs));
+      const unsigned nb = (unsigned)((nt * k1 + kBlock - 1) / kBlock);
+      if (op->real == SCTL_AMD_F64) hipLaunchKernelGGL((normal_dot_kernel<double>), dim3(nb), dim3(kBlock), 0, d.st, (const double*)d.v, (const double*)d.nt, (double*)d.u, nt, k1);
+      else hipLaunchKernelGGL((normal_dot_kernel<float>), dim3(nb), dim3(kBlock), 0, d.st, (const float*)d.v, (const float*)d.nt, (float*)d.u, nt, k1);
+      HIP_TRY(hipGetLastError());
+      result = d.u;
+    }
+    const size_t obytes = (size_t)nt * k1 * rs;
+    char* dst = (char*)v_trg + (size_t)d.t0 * k1 * rs;
+    const char* out = d.stage.take(obytes);
+    HIP_TRY(hipMemcpyAsync((void*)out, result, obytes, hipMemcpyDeviceToHost, d.st));
     HIP_TRY(hipStreamSynchronize(d.st));
     if (!op->perm.empty()) {   // Morton slab -> the caller's target order (a permutation: the device threads write disjoint entries)
       const int64_t* perm = op->perm.data() + d.t0;
-      const int k1 = k.k1;
       if (op->real == SCTL_AMD_F64) {
         double* o = (double*)v_trg; const double* sv = (const double*)out;
         for (int64_t i = 0; i < nt; i++) for (int c = 0; c < k1; c++) { double& e = o[perm[i] * k1 + c]; e = (accumulate ? e : 0.0) + sv[i * k1 + c]; }
@@ -752,10 +815,10 @@ int sctl_amd_op_eval(sctl_amd_op* op, const void* v_src, void* v_trg, int accumu
       return SCTL_AMD_OK;
     }
     if (!accumulate) {
-      std::memcpy(dst, out, vbytes);
+      std::memcpy(dst, out, obytes);
       return SCTL_AMD_OK;
     }
-    const int64_t n = nt * k.k1;
+    const int64_t n = nt * k1;
     if (op->real == SCTL_AMD_F64) { double* o = (double*)dst; const double* s = (const double*)out; for (int64_t i = 0; i < n; i++) o[i] += s[i]; }
     else { float* o = (float*)dst; const float* s = (const float*)out; for (int64_t i = 0; i < n; i++) o[i] += s[i]; }
     return SCTL_AMD_OK;

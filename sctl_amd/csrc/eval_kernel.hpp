@@ -286,3 +286,21 @@ __global__ void __launch_bounds__(kBlock) matrix_batch_kernel(const MatTile* __r
 }
 
 }  // namespace sctl_amd
+
+namespace sctl_amd {
+
+// Far-field pre/post steps of BoundaryIntegralOp::ComputeFarField on the device:
+//   f[s*K0 + k] *= w[s]                                      the quadrature weights     boundary_integral.txx:1040-1052
+//   u[t*K1_ + k] = sum_l v[(t*K1_ + k)*3 + l] * n[t*3 + l]     dot with target normals    boundary_integral.txx:1060-1071
+template <class R> __global__ void __launch_bounds__(kBlock) scale_density_kernel(R* f, const R* w, int64_t n, int k0) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n * k0) f[i] *= w[i / k0];
+}
+template <class R> __global__ void __launch_bounds__(kBlock) normal_dot_kernel(const R* v, const R* nrm, R* u, int64_t nt, int k1r) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= nt * k1r) return;
+  const int64_t t = i / k1r;
+  u[i] = v[i * 3] * nrm[t * 3] + v[i * 3 + 1] * nrm[t * 3 + 1] + v[i * 3 + 2] * nrm[t * 3 + 2];
+}
+
+}  // namespace sctl_amd

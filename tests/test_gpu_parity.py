@@ -334,3 +334,35 @@ def test_host_entries_are_reentrant(O):
     sctl_amd.api.trim()                                              # releases the cached scratch blocks; the library keeps working
     i, name, xt, xs, xn, f, ctx = jobs[0]
     assert rel_l2(sctl_amd.eval_host(name, xt, xs, xn, f, ctx=ctx), O.eval(name, xt, xs, xn, f, ctx=ctx)) <= 1e-12
+
+
+@pytest.mark.parametrize("devs", [(0,), (0, 0)])
+def test_operator_handle_applies_weights_and_target_normals_on_the_device(O, devs):
+    """sctl_amd_op_set_source_weights / _target_normals (the far-field pre/post steps of boundary_integral.txx:1040-1071 on the device):
+    u[t][k] = sum_l (sum_s K(x_t - x_s)[.][k][l] w_s f_s) n_t[l], also with Morton-ordered slabs on several devices, and the
+    setters' lifetime rules (new sources drop the weights, new targets drop the normals)."""
+    name = "Stokes3D-FxT"                                  # 3 -> 9 output components, contracted to 3
+    info = sctl_amd.kernel_info(name)
+    rng = np.random.default_rng(29)
+    nt, ns = 1500, 2100
+    xt, xs, xn, f = _rng_inputs(rng, nt, ns, info, np.float64)
+    w, ntrg = rng.random(ns) * 0.01, rng.random(nt * 3) - 0.5
+    full = O.eval(name, xt, xs, xn, (f.reshape(ns, 3) * w[:, None]).ravel())
+    want = (full.reshape(nt, 3, 3) * ntrg.reshape(nt, 1, 3)).sum(-1).ravel()
+    op = sctl_amd.DirectOp(name, np.float64, devices=devs)
+    op.set_targets(xt)
+    op.set_sources(xs, xn)
+    op.set_source_weights(w)
+    op.set_target_normals(ntrg)
+    u = op.eval(f)
+    assert u.size == nt * 3 and rel_l2(u, want) <= 1e-12, rel_l2(u, want)
+    u2 = op.eval(f, v_trg=u.copy(), accumulate=True)
+    assert rel_l2(u2, 2 * want) <= 1e-12
+    op.set_target_normals(None)                            # cleared: the full 9 components again, still weighted
+    assert rel_l2(op.eval(f), full) <= 1e-12
+    op.set_sources(xs, xn)                                 # new sources drop the weights
+    assert rel_l2(op.eval(f), O.eval(name, xt, xs, xn, f)) <= 1e-12
+    with pytest.raises(sctl_amd.api.SctlAmdError):         # nothing to contract for a scalar kernel
+        lap = sctl_amd.DirectOp("Laplace3D-FxU")
+        lap.set_targets(xt)
+        lap.set_target_normals(ntrg)
