@@ -9,4 +9,5 @@
 #include "sctl_amd/generic-kernel.hpp"
 #include "sctl_amd/kernel_functions.hpp"
 #include "sctl_amd/fmm-wrapper.hpp"
+#include "sctl_amd/boundary_integral.hpp"
 #endif

@@ -33,7 +33,9 @@
 #include <unordered_map>
 #include <vector>
 
-#include "fmm-wrapper.hpp"
+#include "comm.hpp"
+#include "generic-kernel.hpp"
+#include "kernel_functions.hpp"
 
 namespace sctl_amd {
 
