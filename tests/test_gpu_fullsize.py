@@ -17,6 +17,7 @@ def _cloud(seed, Nt, Ns, info, dt=np.float64):
 
 @pytest.mark.parametrize("name,N,dt,tol", [
     ("Laplace3D-FxU", 1 << 20, np.float64, 1e-12),      # BASELINE config 2 size, headline kernel
+    ("Laplace3D-DxU", 1 << 20, np.float64, 1e-12),      # double layer on the tile-centred path at full size
     ("Laplace3D-FDxUdU", 1 << 18, np.float64, 1e-12),   # config 2 functor (SL+DL potential+gradient)
     ("Stokes3D-FxU", 1 << 18, np.float64, 1e-12),       # config 3
     ("Helmholtz3D-FxU", 1 << 17, np.float64, 1e-12),    # config 5 functor
