@@ -322,14 +322,31 @@ struct Helmholtz3D_FxU {
       fastmath::sincos_tab(x, s, c, K.tc, K.table);
     }
   }
-  template <bool MASKED> static __device__ __forceinline__ void sincos_(float x, float, float& s, float& c, const HelmholtzConsts<float>&) { ::sincosf(x, &s, &c); }
+  // fp32: the hardware's sine / cosine / exp2 (v_sin_f32, v_cos_f32, v_exp_f32: ~1e-6 absolute, inputs in revolutions / powers of
+  // two) behind a two-piece reduction, so that the reduced argument keeps 24 bits however many periods x spans.  The phase
+  // error that remains is the rounding of x itself (|x| 6e-8), which libm's exact reduction cannot remove either.
+  template <bool MASKED> static __device__ __forceinline__ void sincos_(float x, float, float& s, float& c, const HelmholtzConsts<float>&) {
+    const float c_hi = 0.15915494f, c_lo = 6.4206383e-9f;       // 1/(2 pi) = c_hi + c_lo
+    const float n = __builtin_rintf(x * c_hi);
+    float fr = __builtin_fmaf(x, c_hi, -n);
+    fr = __builtin_fmaf(x, c_lo, fr);
+    s = __builtin_amdgcn_sinf(fr);
+    c = __builtin_amdgcn_cosf(fr);
+  }
   // exp(-Im k r): r >= 0 is clamped to 800/|Im k| (one v_min_f64; a NaN distance turns into the cap, but then rinv is NaN
   // too and the product stays NaN), so the argument handed to the table code is within its +-800 range
   static __device__ __forceinline__ double exp_(double r, const KerCtx& ctx, const HelmholtzConsts<double>& K) {
     const double rc = __builtin_fmin(r, 800.0 / __builtin_fabs(ctx.v[1]));
     return fastmath::exp_tab_clamped(-ctx.v[1] * rc, K.tc, K.table);
   }
-  static __device__ __forceinline__ float exp_(float r, const KerCtx& ctx, const HelmholtzConsts<float>&) { return ::expf(-float(ctx.v[1]) * r); }
+  static __device__ __forceinline__ float exp_(float r, const KerCtx& ctx, const HelmholtzConsts<float>&) {
+    const float x = -float(ctx.v[1]) * r;
+    const float l_hi = 1.4426950f, l_lo = 1.9259630e-8f;        // log2(e) = l_hi + l_lo
+    const float n = __builtin_fminf(__builtin_fmaxf(__builtin_rintf(x * l_hi), -300.0f), 300.0f);
+    float fr = __builtin_fmaf(x, l_hi, -n);
+    fr = __builtin_fmaf(x, l_lo, fr);
+    return __builtin_ldexpf(__builtin_amdgcn_exp2f(fr), (int)n);   // |x| beyond the clamp: fr is huge, exp2 gives 0 / inf as it should
+  }
 };
 
 }  // namespace sctl_amd

@@ -21,3 +21,4 @@ def run(N, dt, k, reps=2):
 for N in (1<<18,):
     run(N, torch.float64, [7.5, 0.3]); run(N, torch.float64, [7.5, 0.0])
 
+run(1 << 18, torch.float32, [7.5, 0.3]); run(1 << 18, torch.float32, [7.5, 0.0])
