@@ -240,7 +240,9 @@ def main():
                        "partition": "targets block-partitioned (Morton order) over %d GPU(s), sources replicated, %s" %
                                     (world, "one RCCL all-gather of the potential slabs per step" if world > 1 else "no collective"),
                        "launch": plan},
-            "roofline": {"bound": "fp64_valu" if dtype == "f64" else "fp32_valu", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+            # compute-bound: the contract's label for that is "mfma"; on gfx950 the fp64 (fp32) vector pipe this kernel runs on
+            # has the same dense peak as the fp64 (fp32) MFMA path, 78.6 (157.3) TFLOP/s, and shares its issue slots
+            "roofline": {"bound": "mfma", "pipe": "fp64 VALU" if dtype == "f64" else "fp32 VALU", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": read_traffic(args.workload) if world == 1 else None,
                          "flops_per_pair": fpp, "kernel_ms": k_ms,
                          "note": "vector-FMA bound (SURVEY.md §8d): algorithmic flops = pairs x (3 + FLOPS() + 2 K0 K1); "
