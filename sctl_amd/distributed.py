@@ -126,7 +126,12 @@ class ShardedDirectSum:
             out.copy_(slab)
             return out
         self._local_targets(r_trg)
-        gathered = out if self._perm is None else r_trg.new_empty(Nt * k1)
+        if self._perm is None:
+            gathered = out
+        else:                                           # staging buffer for the Morton-ordered gather, kept between calls
+            if getattr(self, "_gathered", None) is None or self._gathered.numel() != Nt * k1 or self._gathered.dtype != r_trg.dtype or self._gathered.device != r_trg.device:
+                self._gathered = r_trg.new_empty(Nt * k1)
+            gathered = self._gathered
         if Nt % self.world == 0:
             self.dist.all_gather_into_tensor(gathered, slab, group=self.group)      # equal slabs: one fused collective
         else:
@@ -140,7 +145,7 @@ class ShardedDirectSum:
                 gathered[off:off + sizes[g]] = recv[g * pad:g * pad + sizes[g]]
                 off += sizes[g]
         if self._perm is not None:
-            out.view(Nt, k1)[self._perm] = gathered.view(Nt, k1)                    # Morton order -> caller's order
+            out.view(Nt, k1).index_copy_(0, self._perm, gathered.view(Nt, k1))      # Morton order -> caller's order
         return out
 
 
