@@ -250,6 +250,21 @@ def main():
             "sctl_gflops": value * info["flops"] / 1e9,   # the reference's own Profile convention (generic-kernel.txx:188)
             "pct_of_peak_all_gpus": 100.0 * value * fpp / (peak * 1e12 * world),
         }
+        if world == 1 and args.digits < 0 and dtype == "f64":
+            # Informational, outside the timed region and not part of `value`: the same workload at the accuracy the reference's
+            # own callers ask for — ParticleFMM defaults to 10 digits (fmm-wrapper.txx:204), BoundaryIntegralOp to tol 1e-10 (:500).
+            op10 = ShardedDirectSum(kernel, ctx=ctx, digits=10)
+            op10.eval_slab(r_trg, r_src, n_src, v_src, out_slab)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(2):
+                op10.eval_slab(r_trg, r_src, n_src, v_src, out_slab)
+            e1.record()
+            torch.cuda.synchronize()
+            ms10 = e0.elapsed_time(e1) / 2
+            line["at_reference_callers_accuracy"] = {"digits": 10, "ms_per_step": ms10, "value": pairs_per_step / (ms10 * 1e-3),
+                                                     "frac": pairs_per_step * fpp / (ms10 * 1e-3) / 1e12 / peak}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(kernel, N, dtype)
