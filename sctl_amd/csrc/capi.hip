@@ -158,7 +158,7 @@ bool use_centered(const KernelEntry& k, int real, int64_t Nt, int64_t Ns, int64_
 
 template <class R>
 int run_centered(const KernelEntry& k, int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* xn, const R* f, R* v, int mode, hipStream_t st) {
-  HIP_TRY(eval_centered<R>(k.id, Nt, Ns, xt, xs, xn, f, v, k.scale, mode, cu_count(), st));
+  HIP_TRY(eval_centered<R>(k.id, Nt, Ns, xt, xs, xn, f, v, k.scale / k.acc_factor[mode], mode, cu_count(), st));
   g_pairs += Nt * Ns;
   g_flops += Nt * Ns * k.flops;
   return SCTL_AMD_OK;
@@ -174,7 +174,7 @@ int eval_device_t(const KernelEntry& k, int real, int64_t Nt, int64_t Ns, const 
   if (use_centered(k, real, Nt, Ns, nt_whole)) return run_centered<R>(k, Nt, Ns, xt, xs, xn, f, v, mode, st);
   EvalArgs<R> a{};
   a.Nt = Nt; a.Ns = Ns; a.xt = xt; a.xs = xs; a.xn = xn; a.f = f; a.v_trg = v; a.partial = nullptr;
-  a.chunk = p.chunk; a.scale = (R)k.scale; a.ctx = make_ctx(k, ctx);
+  a.chunk = p.chunk; a.scale = (R)(k.scale / k.acc_factor[mode]); a.ctx = make_ctx(k, ctx);   // pair() of this mode may accumulate a multiple (launch.hpp)
   if (p.splits > 1) {
     void* ws = nullptr;
     HIP_TRY(workspace_acquire(st, (size_t)p.workspace_bytes, &ws));   // the block of this stream (workspace.hpp), not the HIP pool
@@ -186,7 +186,7 @@ int eval_device_t(const KernelEntry& k, int real, int64_t Nt, int64_t Ns, const 
   if (p.splits > 1) {
     const int64_t n = Nt * k.k1;
     hipLaunchKernelGGL((reduce_splits_kernel<R>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, v, (const R*)a.partial, n,
-                       p.splits, (R)k.scale);
+                       p.splits, (R)(k.scale / k.acc_factor[mode]));
     HIP_TRY(hipGetLastError());
   }
   g_pairs += Nt * Ns;
@@ -201,7 +201,7 @@ int matrix_device_t(const KernelEntry& k, int real, int64_t Nt, int64_t Ns, cons
   (void)hipGetLastError();
   const int mode = mode_for(real, digits);
   const dim3 grid((unsigned)((Nt + kBlock - 1) / kBlock), (unsigned)(Ns < 65535 ? Ns : 65535));
-  pick_matrix<R>(k, mode)(Nt, Ns, xt, xs, xn, M, (R)k.scale, make_ctx(k, ctx), grid, st);
+  pick_matrix<R>(k, mode)(Nt, Ns, xt, xs, xn, M, (R)(k.scale / k.acc_factor[mode]), make_ctx(k, ctx), grid, st);
   HIP_TRY(hipGetLastError());
   g_pairs += Nt * Ns;
   g_flops += Nt * Ns * k.flops;
@@ -617,10 +617,10 @@ int sctl_amd_kernel_matrix_batch_host(int kernel, int real, int64_t nbatch, cons
   const int mode = mode_for(real, digits);
   if (real == SCTL_AMD_F64)
     k->matrix_batch_f64[mode]((const MatTile*)hs.buf[3].p, (int64_t)tiles.size(), (const double*)hs.buf[0].p, (const double*)hs.buf[1].p, (const double*)hs.buf[2].p,
-                              (double*)hs.buf[4].p, k->scale, make_ctx(*k, ctx), hs.st.s);
+                              (double*)hs.buf[4].p, k->scale / k->acc_factor[mode], make_ctx(*k, ctx), hs.st.s);
   else
     k->matrix_batch_f32[mode]((const MatTile*)hs.buf[3].p, (int64_t)tiles.size(), (const float*)hs.buf[0].p, (const float*)hs.buf[1].p, (const float*)hs.buf[2].p,
-                              (float*)hs.buf[4].p, (float)k->scale, make_ctx(*k, ctx), hs.st.s);
+                              (float*)hs.buf[4].p, (float)(k->scale / k->acc_factor[mode]), make_ctx(*k, ctx), hs.st.s);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(M, hs.buf[4].p, b_m, hipMemcpyDeviceToHost, hs.st.s));   // M is written once by this call: no staging needed for a D2H
   HIP_TRY(hipStreamSynchronize(hs.st.s));

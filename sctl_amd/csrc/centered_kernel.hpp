@@ -80,7 +80,7 @@ template <class R> struct CenteredFxU {      // u += f / r
   static __device__ __forceinline__ Extra load_extra(const R* base, int s) { return Extra{base[s]}; }
   template <int MODE> static __device__ __forceinline__ void far_pair(R& acc, const R (&m2x)[3], R tt, const R (&b)[4], const Extra& e, const RsqConst<R>& K) {
     const R r2 = fma_(m2x[0], b[0], fma_(m2x[1], b[1], fma_(m2x[2], b[2], tt + b[3])));
-    acc = fma_(e.f, rsqrt_masked<MODE, false>(r2, K), acc);
+    acc = fma_(e.f, (MODE == 1) ? rsqrt_newton2<false>(r2, K) : rsqrt_masked<MODE, false>(r2, K), acc);   // MODE 1: 2/r, as Ker::pair (acc_factor)
   }
 };
 template <class R> struct CenteredDxU {      // u += ((x_t - x_s).n f) / r^3, with (x_t - x_s).n f = x_t'.nf - x_s'.nf
@@ -99,7 +99,7 @@ template <class R> struct CenteredDxU {      // u += ((x_t - x_s).n f) / r^3, wi
   }
   template <int MODE> static __device__ __forceinline__ void far_pair(R& acc, const R (&m2x)[3], R tt, const R (&b)[4], const Extra& e, const RsqConst<R>& K) {
     const R r2 = fma_(m2x[0], b[0], fma_(m2x[1], b[1], fma_(m2x[2], b[2], tt + b[3])));
-    const R y = rsqrt_masked<MODE, false>(r2, K);
+    const R y = (MODE == 1) ? rsqrt_newton2<false>(r2, K) : rsqrt_masked<MODE, false>(r2, K);                // MODE 1: 2/r, as Ker::pair (acc_factor)
     const R dn = fma_(m2x[0], e.g[0], fma_(m2x[1], e.g[1], fma_(m2x[2], e.g[2], e.g[3])));
     acc = fma_(dn, y * y * y, acc);
   }

@@ -17,6 +17,7 @@ struct KernelEntry {
   const char* name;
   int id, k0, k1, nd, flops, nrec, ctx_bytes;
   double scale;
+  double acc_factor[kNumMode];   // pair() of mode m accumulates acc_factor[m] x the kernel value: the launch scale is scale / acc_factor[m]
   EvalLaunch<double> eval_f64[kNumMode][kNumT];
   EvalLaunch<float> eval_f32[kNumMode][kNumT];     // modes 0 and 1 only (mode 2 aliases mode 1)
   MatrixLaunch<double> matrix_f64[kNumMode];
@@ -42,6 +43,7 @@ template <class Ker> KernelEntry make_entry(int ctx_bytes) {
   KernelEntry e{};
   e.name = Ker::NAME; e.id = Ker::ID; e.k0 = Ker::K0; e.k1 = Ker::K1; e.nd = Ker::ND; e.flops = Ker::FLOPS; e.nrec = Ker::NREC;
   e.ctx_bytes = ctx_bytes; e.scale = Ker::scale();
+  for (int m = 0; m < kNumMode; m++) e.acc_factor[m] = Ker::acc_factor(m);
 #define SCTL_AMD_ROW(R, arr, M, MM) \
   arr[M][0] = launch_eval<Ker, R, MM, 1>; arr[M][1] = launch_eval<Ker, R, MM, 2>; arr[M][2] = launch_eval<Ker, R, MM, 4>;
   SCTL_AMD_ROW(double, e.eval_f64, 0, 0) SCTL_AMD_ROW(double, e.eval_f64, 1, 1) SCTL_AMD_ROW(double, e.eval_f64, 2, 2)

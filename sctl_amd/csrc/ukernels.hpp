@@ -129,17 +129,28 @@ template <> __device__ __forceinline__ float fma_<float>(float a, float b, float
 template <class R> __device__ __forceinline__ R len2(const R (&d)[3]) { return fma_(d[2], d[2], fma_(d[1], d[1], d[0] * d[0])); }
 template <class R> __device__ __forceinline__ R dot3(const R (&d)[3], const R* v) { return fma_(d[2], v[2], fma_(d[1], v[1], d[0] * v[0])); }
 
+// MODE 1 for kernels whose terms all carry the same power of 1/r: the Newton step without its halving, y0 (3 - r2 y0^2) = 2/r
+// (>= 14 digits), three instructions instead of four.  The factor 2^p goes into the scale applied once per target
+// (Ker::acc_factor): this is the accuracy ParticleFMM (10 digits) and BoundaryIntegralOp (tol 1e-10) ask for by default, so it is
+// the form the reference's own callers run.  With the masked seed y0 = 0 the result is 0, so the r = 0 rule survives.
+template <bool MASKED, class R> __device__ __forceinline__ R rsqrt_newton2(R r2, const RsqConst<R>& K) {
+  const R y = rsqrt_masked<0, MASKED>(r2, K);
+  const R a = r2 * y;
+  return y * fma_(-a, y, R(3));
+}
+
 // ---- Laplace single layer: u = f / r          (kernel_functions.hpp:15-31) -------------------------------
 struct Laplace3D_FxU {
   static constexpr int ID = 0, K0 = 1, K1 = 1, ND = 0, NREC = 4, FLOPS = 6;
   static constexpr const char* NAME = "Laplace3D-FxU";
   template <class R> using Consts = DefaultConsts<R>;
   static constexpr double scale() { return 1 / (4 * kPi); }
+  static constexpr double acc_factor(int mode) { return mode == 1 ? 2 : 1; }   // MODE 1 accumulates f (2/r)
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0];
   }
   template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const Consts<R>& K) {
-    const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K.rsq);
+    const R rinv = (MODE == 1) ? rsqrt_newton2<MASKED>(len2(d), K.rsq) : rsqrt_masked<MODE, MASKED>(len2(d), K.rsq);   // MODE 1: 2/r
     acc[0] = fma_(rec[3], rinv, acc[0]);
   }
 };
@@ -150,11 +161,12 @@ struct Laplace3D_DxU {
   static constexpr const char* NAME = "Laplace3D-DxU";
   template <class R> using Consts = DefaultConsts<R>;
   static constexpr double scale() { return 1 / (4 * kPi); }
+  static constexpr double acc_factor(int mode) { return mode == 1 ? 8 : 1; }   // MODE 1 accumulates (r.n f) (2/r)^3
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R* n, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = n[0] * f[0]; rec[4] = n[1] * f[0]; rec[5] = n[2] * f[0];
   }
   template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const Consts<R>& K) {
-    const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K.rsq);
+    const R rinv = (MODE == 1) ? rsqrt_newton2<MASKED>(len2(d), K.rsq) : rsqrt_masked<MODE, MASKED>(len2(d), K.rsq);   // MODE 1: 2/r
     const R rinv3 = rinv * rinv * rinv;
     acc[0] = fma_(dot3(d, rec + 3), rinv3, acc[0]);
   }
@@ -166,6 +178,7 @@ struct Laplace3D_FxdU {
   static constexpr const char* NAME = "Laplace3D-FxdU";
   template <class R> using Consts = DefaultConsts<R>;
   static constexpr double scale() { return -1 / (4 * kPi); }
+  static constexpr double acc_factor(int /*mode*/) { return 1; }   // what pair() accumulates, relative to the kernel value
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0];
   }
@@ -182,6 +195,7 @@ struct Stokes3D_FxU {
   static constexpr const char* NAME = "Stokes3D-FxU";
   template <class R> using Consts = DefaultConsts<R>;
   static constexpr double scale() { return 1 / (8 * kPi); }
+  static constexpr double acc_factor(int /*mode*/) { return 1; }   // what pair() accumulates, relative to the kernel value
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0]; rec[4] = f[1]; rec[5] = f[2];
   }
@@ -198,6 +212,7 @@ struct Stokes3D_DxU {
   static constexpr const char* NAME = "Stokes3D-DxU";
   template <class R> using Consts = DefaultConsts<R>;
   static constexpr double scale() { return 3 / (4 * kPi); }
+  static constexpr double acc_factor(int /*mode*/) { return 1; }   // what pair() accumulates, relative to the kernel value
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R* n, const R* f) {
     for (int k = 0; k < 3; k++) { rec[k] = x[k]; rec[3 + k] = n[k]; rec[6 + k] = f[k]; }
     rec[9] = 0;
@@ -216,6 +231,7 @@ struct Stokes3D_FxT {
   static constexpr const char* NAME = "Stokes3D-FxT";
   template <class R> using Consts = DefaultConsts<R>;
   static constexpr double scale() { return -3 / (4 * kPi); }
+  static constexpr double acc_factor(int /*mode*/) { return 1; }   // what pair() accumulates, relative to the kernel value
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0]; rec[4] = f[1]; rec[5] = f[2];
   }
@@ -236,6 +252,7 @@ struct Stokes3D_FSxU {
   static constexpr const char* NAME = "Stokes3D-FSxU";
   template <class R> using Consts = DefaultConsts<R>;
   static constexpr double scale() { return 1 / (8 * kPi); }
+  static constexpr double acc_factor(int /*mode*/) { return 1; }   // what pair() accumulates, relative to the kernel value
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0]; rec[4] = f[1]; rec[5] = f[2]; rec[6] = f[3]; rec[7] = 0;
   }
@@ -252,6 +269,7 @@ struct Stokes3D_FxUP {
   static constexpr const char* NAME = "Stokes3D-FxUP";
   template <class R> using Consts = DefaultConsts<R>;
   static constexpr double scale() { return 1 / (8 * kPi); }
+  static constexpr double acc_factor(int /*mode*/) { return 1; }   // what pair() accumulates, relative to the kernel value
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0]; rec[4] = f[1]; rec[5] = f[2];
   }
@@ -271,6 +289,7 @@ struct Laplace3D_FDxUdU {
   static constexpr const char* NAME = "Laplace3D-FDxUdU";
   template <class R> using Consts = DefaultConsts<R>;
   static constexpr double scale() { return 1 / (4 * kPi); }
+  static constexpr double acc_factor(int /*mode*/) { return 1; }   // what pair() accumulates, relative to the kernel value
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R* n, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2];
     rec[3] = n[0] * f[1]; rec[4] = n[1] * f[1]; rec[5] = n[2] * f[1]; rec[6] = f[0]; rec[7] = 0;
@@ -293,6 +312,7 @@ struct Helmholtz3D_FxU {
   static constexpr const char* NAME = "Helmholtz3D-FxU";
   template <class R> using Consts = HelmholtzConsts<R>;
   static constexpr double scale() { return 1 / (4 * kPi); }
+  static constexpr double acc_factor(int /*mode*/) { return 1; }   // what pair() accumulates, relative to the kernel value
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0]; rec[4] = f[1]; rec[5] = 0;
   }
