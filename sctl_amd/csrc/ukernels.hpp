@@ -178,12 +178,12 @@ struct Laplace3D_FxdU {
   static constexpr const char* NAME = "Laplace3D-FxdU";
   template <class R> using Consts = DefaultConsts<R>;
   static constexpr double scale() { return -1 / (4 * kPi); }
-  static constexpr double acc_factor(int /*mode*/) { return 1; }   // what pair() accumulates, relative to the kernel value
+  static constexpr double acc_factor(int mode) { return mode == 1 ? 8 : 1; }   // MODE 1 accumulates f r (2/r)^3
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0];
   }
   template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const Consts<R>& K) {
-    const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K.rsq);
+    const R rinv = (MODE == 1) ? rsqrt_newton2<MASKED>(len2(d), K.rsq) : rsqrt_masked<MODE, MASKED>(len2(d), K.rsq);   // MODE 1: 2/r
     const R t = rinv * rinv * rinv * rec[3];
     for (int j = 0; j < 3; j++) acc[j] = fma_(t, d[j], acc[j]);
   }
