@@ -212,13 +212,13 @@ struct Stokes3D_DxU {
   static constexpr const char* NAME = "Stokes3D-DxU";
   template <class R> using Consts = DefaultConsts<R>;
   static constexpr double scale() { return 3 / (4 * kPi); }
-  static constexpr double acc_factor(int /*mode*/) { return 1; }   // what pair() accumulates, relative to the kernel value
+  static constexpr double acc_factor(int mode) { return mode == 1 ? 32 : 1; }   // MODE 1 accumulates (...) (2/r)^5
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R* n, const R* f) {
     for (int k = 0; k < 3; k++) { rec[k] = x[k]; rec[3 + k] = n[k]; rec[6 + k] = f[k]; }
     rec[9] = 0;
   }
   template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const Consts<R>& K) {
-    const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K.rsq);
+    const R rinv = (MODE == 1) ? rsqrt_newton2<MASKED>(len2(d), K.rsq) : rsqrt_masked<MODE, MASKED>(len2(d), K.rsq);   // MODE 1: 2/r
     const R rinv2 = rinv * rinv;
     const R t = dot3(d, rec + 3) * dot3(d, rec + 6) * (rinv2 * rinv2 * rinv);
     for (int j = 0; j < 3; j++) acc[j] = fma_(t, d[j], acc[j]);
@@ -231,12 +231,12 @@ struct Stokes3D_FxT {
   static constexpr const char* NAME = "Stokes3D-FxT";
   template <class R> using Consts = DefaultConsts<R>;
   static constexpr double scale() { return -3 / (4 * kPi); }
-  static constexpr double acc_factor(int /*mode*/) { return 1; }   // what pair() accumulates, relative to the kernel value
+  static constexpr double acc_factor(int mode) { return mode == 1 ? 32 : 1; }   // MODE 1 accumulates (...) (2/r)^5
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0]; rec[4] = f[1]; rec[5] = f[2];
   }
   template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const Consts<R>& K) {
-    const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K.rsq);
+    const R rinv = (MODE == 1) ? rsqrt_newton2<MASKED>(len2(d), K.rsq) : rsqrt_masked<MODE, MASKED>(len2(d), K.rsq);   // MODE 1: 2/r
     const R rinv2 = rinv * rinv;
     const R t = dot3(d, rec + 3) * (rinv2 * rinv2 * rinv);
     for (int j = 0; j < 3; j++) {
