@@ -1,0 +1,22 @@
+"""Every kernel at 2^18 x 2^18 fp64, full precision and at the 10 digits SCTL's ParticleFMM / BoundaryIntegralOp request."""
+import os, sys, torch, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sctl_amd
+def run(name, N, digits, reps=3):
+    info = sctl_amd.kernel_info(name)
+    g = torch.Generator(device='cuda').manual_seed(0)
+    dt = torch.float64
+    xt = torch.rand(N*3, dtype=dt, device='cuda', generator=g); xs = torch.rand(N*3, dtype=dt, device='cuda', generator=g)
+    xn = torch.rand(N*info['nd'], dtype=dt, device='cuda', generator=g)-0.5; f = torch.rand(N*info['k0'], dtype=dt, device='cuda', generator=g)-0.5
+    ctx = np.array([7.5,0.3]) if name.startswith('Helm') else None
+    v = torch.zeros(N*info['k1'], dtype=dt, device='cuda')
+    sctl_amd.eval_device(name, xt, xs, xn, f, v_trg=v, ctx=ctx, digits=digits); torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): sctl_amd.eval_device(name, xt, xs, xn, f, v_trg=v, ctx=ctx, digits=digits)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)/reps
+    return ms, N*N/(ms*1e-3)*sctl_amd.flops_per_pair(name)/78.6e12*100
+for k in sctl_amd.KERNEL_NAMES:
+    a, b = run(k, 1 << 18, -1), run(k, 1 << 18, 10)
+    print("%-18s 2^18 x 2^18 fp64: full precision %8.2f ms %5.1f %% of peak | 10 digits %8.2f ms %5.1f %% of peak (%+.1f %%)" % (k, a[0], a[1], b[0], b[1], 100 * (a[0] / b[0] - 1)), flush=True)
