@@ -20,7 +20,7 @@ namespace sctl_amd {
 // centered.hip
 template <class R>
 hipError_t eval_centered(int kernel_id, int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* xn, const R* f, R* v_trg, double scale, int mode,
-                         int cus, hipStream_t st);
+                         int cus, hipStream_t st, bool presorted);
 void centered_plan(int64_t Nt, int64_t Ns, int cus, int* T, int* splits, int64_t* chunk);
 namespace {
 
@@ -141,11 +141,17 @@ KerCtx make_ctx(const KernelEntry& k, const void* ctx) {
 // Tile-centred fast path (centered_kernel.hpp): Laplace single layer (fp64 and fp32) on problems large enough to amortise the
 // Morton sort of the targets.  SCTL_AMD_CENTERED=0 in the environment forces the exact kernel (used for A/B checks).
 // nt_whole: size of the target set the Nt targets were cut from as a spatially compact slab (= Nt for a whole set).
-bool use_centered(const KernelEntry& k, int real, int64_t Nt, int64_t Ns, int64_t nt_whole = 0) {
+bool has_centered_path(const KernelEntry& k) { return k.id == SCTL_AMD_LAPLACE3D_FXU || k.id == SCTL_AMD_LAPLACE3D_DXU; }
+constexpr int64_t kPresortMinTargets = 1 << 17;   // sctl_amd_op_* keeps the targets of such kernels in Morton order from this size on
+
+bool use_centered(const KernelEntry& k, int real, int64_t Nt, int64_t Ns, int64_t nt_whole = 0, bool presorted = false) {
   const char* e = std::getenv("SCTL_AMD_CENTERED");   // read per call so that a test can A/B both paths in one process
   const bool enabled = !(e && e[0] == '0'), forced = (e && e[0] == '1');
-  if (!enabled || (k.id != SCTL_AMD_LAPLACE3D_FXU && k.id != SCTL_AMD_LAPLACE3D_DXU) || Nt >= (int64_t(1) << 32)) return false;
+  if (!enabled || !has_centered_path(k) || Nt >= (int64_t(1) << 32)) return false;
   if (forced) return Nt >= 128 && Ns >= 64;
+  // (targets already in Morton order — `presorted`, no per-call sort/gather/scatter — do not move the crossover: at 2^17 x 2^17 the
+  // centred kernel itself is level with the exact one, 8.14 vs 8.05 ms, because ~10 % of the sources are near; tools/presorted_threshold.py)
+  (void)presorted;
   // What decides is the target DENSITY: with too few targets in the domain the 128 targets of a wave span so much of it
   // that many sources are "near" and the exact kernel wins.  Measured with the near threshold 4 Rt^2 (tools/centred_threshold.py,
   // profiles/r01d_centred_threshold.txt; fp64, exact vs centred): 2^18 x 2^18 34.4 vs 32.1 ms, 2^20 x 2^14 8.69 vs 8.38 ms,
@@ -157,8 +163,8 @@ bool use_centered(const KernelEntry& k, int real, int64_t Nt, int64_t Ns, int64_
 }
 
 template <class R>
-int run_centered(const KernelEntry& k, int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* xn, const R* f, R* v, int mode, hipStream_t st) {
-  HIP_TRY(eval_centered<R>(k.id, Nt, Ns, xt, xs, xn, f, v, k.scale / k.acc_factor[mode], mode, cu_count(), st));
+int run_centered(const KernelEntry& k, int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* xn, const R* f, R* v, int mode, hipStream_t st, bool presorted) {
+  HIP_TRY(eval_centered<R>(k.id, Nt, Ns, xt, xs, xn, f, v, k.scale / k.acc_factor[mode], mode, cu_count(), st, presorted));
   g_pairs += Nt * Ns;
   g_flops += Nt * Ns * k.flops;
   return SCTL_AMD_OK;
@@ -166,12 +172,12 @@ int run_centered(const KernelEntry& k, int64_t Nt, int64_t Ns, const R* xt, cons
 
 template <class R>
 int eval_device_t(const KernelEntry& k, int real, int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* xn, const R* f, R* v, int digits,
-                  const void* ctx, hipStream_t st, int64_t nt_whole = 0) {
+                  const void* ctx, hipStream_t st, int64_t nt_whole = 0, bool presorted = false) {
   if (Nt == 0 || Ns == 0) return SCTL_AMD_OK;   // nothing to add (generic-kernel.txx:153-186 degenerates to v_trg += 0)
   (void)hipGetLastError();                      // drop a stale error of an earlier, unrelated runtime call on this thread
   const Plan p = make_plan(k, real, Nt, Ns);
   const int mode = mode_for(real, digits);
-  if (use_centered(k, real, Nt, Ns, nt_whole)) return run_centered<R>(k, Nt, Ns, xt, xs, xn, f, v, mode, st);
+  if (use_centered(k, real, Nt, Ns, nt_whole, presorted)) return run_centered<R>(k, Nt, Ns, xt, xs, xn, f, v, mode, st, presorted);
   EvalArgs<R> a{};
   a.Nt = Nt; a.Ns = Ns; a.xt = xt; a.xs = xs; a.xn = xn; a.f = f; a.v_trg = v; a.partial = nullptr;
   a.chunk = p.chunk; a.scale = (R)(k.scale / k.acc_factor[mode]); a.ctx = make_ctx(k, ctx);   // pair() of this mode may accumulate a multiple (launch.hpp)
@@ -675,10 +681,11 @@ int sctl_amd_op_set_targets(sctl_amd_op* op, int64_t Nt, const void* r_trg) {
   op->have_trg_normals = false;   // normals belong to a target set: set them again after new targets
   int g = 0;
   for (OpDevice& d : op->devs) { d.t0 = Nt * g / G; d.t1 = Nt * (g + 1) / G; g++; }   // fmm-wrapper.txx:507
-  // several devices: slabs of the Morton-ordered targets (coordinates gathered into sorted order once, here)
+  // several devices, or a kernel with a tile-centred path: the targets are kept in Morton order (coordinates gathered into sorted
+  // order once, here), so that slabs are compact and an evaluation needs no sort of its own
   std::vector<char> sorted;
   op->perm.clear();
-  if (G > 1 && Nt > 0) {
+  if ((G > 1 || (has_centered_path(*op->k) && Nt >= kPresortMinTargets)) && Nt > 0) {
     if (op->real == SCTL_AMD_F64) morton_permutation((const double*)r_trg, Nt, op->perm);
     else morton_permutation((const float*)r_trg, Nt, op->perm);
     sorted.resize((size_t)Nt * 3 * rs);
@@ -782,10 +789,10 @@ int sctl_amd_op_eval(sctl_amd_op* op, const void* v_src, void* v_trg, int accumu
     int rc;
     if (op->real == SCTL_AMD_F64)
       rc = eval_device_t<double>(k, op->real, nt, Ns, (const double*)d.xt, (const double*)d.xs, (const double*)d.xn, (const double*)d.f, (double*)d.v,
-                                 digits, ctx, d.st, op->perm.empty() ? 0 : op->Nt);
+                                 digits, ctx, d.st, op->perm.empty() ? 0 : op->Nt, !op->perm.empty());
     else
       rc = eval_device_t<float>(k, op->real, nt, Ns, (const float*)d.xt, (const float*)d.xs, (const float*)d.xn, (const float*)d.f, (float*)d.v, digits,
-                                ctx, d.st, op->perm.empty() ? 0 : op->Nt);
+                                ctx, d.st, op->perm.empty() ? 0 : op->Nt, !op->perm.empty());
     if (rc) return rc;
     int k1 = k.k1;            // components per target that go back to the host
     const void* result = d.v;

@@ -45,11 +45,31 @@ void centered_plan(int64_t Nt, int64_t Ns, int cus, int* T, int* splits, int64_t
 
 template <class CP, class R>
 hipError_t eval_centered_t(int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* xn, const R* f, R* v_trg, double scale_d, int mode, int cus,
-                           hipStream_t st) {
+                           hipStream_t st, bool presorted) {
   const R scale = (R)scale_d;
   int T, splits;
   int64_t chunk;
   centered_plan(Nt, Ns, cus, &T, &splits, &chunk);
+  if (presorted) {   // the caller keeps the targets in Morton order (sctl_amd_op_*): no sort, no gather, results in place
+    R* partial = nullptr;
+    if (splits > 1) {
+      void* base = nullptr;
+      CENTERED_TRY(workspace_acquire(st, sizeof(R) * (size_t)splits * (size_t)Nt, &base));
+      partial = (R*)base;
+    }
+    EvalArgs<R> a{};
+    a.Nt = Nt; a.Ns = Ns; a.xt = xt; a.xs = xs; a.xn = xn; a.f = f; a.v_trg = v_trg; a.partial = partial;
+    a.chunk = chunk; a.scale = scale;
+    a.ctx.v[0] = kNearFactor2;
+    const dim3 grid((unsigned)((Nt + (int64_t)kWaveBlock * T - 1) / ((int64_t)kWaveBlock * T)), (unsigned)splits);
+    if (mode == 0) launch_centered<CP, R, 0>(a, grid, st);
+    else if (mode == 1) launch_centered<CP, R, 1>(a, grid, st);
+    else launch_centered<CP, R, (sizeof(R) == 8 ? 2 : 1)>(a, grid, st);
+    CENTERED_TRY(hipGetLastError());
+    if (splits > 1)
+      hipLaunchKernelGGL((reduce_splits_kernel<R>), dim3((unsigned)((Nt + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, v_trg, (const R*)partial, Nt, splits, scale);
+    return hipGetLastError();
+  }
   const int nblk_box = 256;
   const unsigned nb = (unsigned)((Nt + kBlock - 1) / kBlock);
   size_t tmp_bytes = 0;   // size query only: no pointer is dereferenced
@@ -95,11 +115,11 @@ hipError_t eval_centered_t(int64_t Nt, int64_t Ns, const R* xt, const R* xs, con
 // kernel id -> policy
 template <class R>
 hipError_t eval_centered(int kernel_id, int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* xn, const R* f, R* v_trg, double scale, int mode, int cus,
-                         hipStream_t st) {
-  if (kernel_id == Laplace3D_DxU::ID) return eval_centered_t<CenteredDxU<R>, R>(Nt, Ns, xt, xs, xn, f, v_trg, scale, mode, cus, st);
-  return eval_centered_t<CenteredFxU<R>, R>(Nt, Ns, xt, xs, xn, f, v_trg, scale, mode, cus, st);
+                         hipStream_t st, bool presorted) {
+  if (kernel_id == Laplace3D_DxU::ID) return eval_centered_t<CenteredDxU<R>, R>(Nt, Ns, xt, xs, xn, f, v_trg, scale, mode, cus, st, presorted);
+  return eval_centered_t<CenteredFxU<R>, R>(Nt, Ns, xt, xs, xn, f, v_trg, scale, mode, cus, st, presorted);
 }
-template hipError_t eval_centered<double>(int, int64_t, int64_t, const double*, const double*, const double*, const double*, double*, double, int, int, hipStream_t);
-template hipError_t eval_centered<float>(int, int64_t, int64_t, const float*, const float*, const float*, const float*, float*, double, int, int, hipStream_t);
+template hipError_t eval_centered<double>(int, int64_t, int64_t, const double*, const double*, const double*, const double*, double*, double, int, int, hipStream_t, bool);
+template hipError_t eval_centered<float>(int, int64_t, int64_t, const float*, const float*, const float*, const float*, float*, double, int, int, hipStream_t, bool);
 
 }  // namespace sctl_amd

@@ -138,13 +138,16 @@ def test_one_process_multi_device_slabs_follow_the_morton_curve(O):
     sel = rng.choice(n, 200, replace=False)
     ref = O.eval("Laplace3D-FxU", xt.reshape(n, 3)[sel].ravel().copy(), xs, None, f)
     assert rel_l2(two[sel], ref) <= 1e-12
-    op = sctl_amd.DirectOp("Laplace3D-FxU", np.float64, devices=(0, 0, 0))
-    op.set_targets(xt)
-    op.set_sources(xs)
-    u = np.full(n, 0.5)
-    op.eval(f, u, accumulate=True)
-    assert rel_l2(u - 0.5, one) <= 1e-13
-    op.eval(f, u, accumulate=False)                      # EvalDirect: overwrite
-    assert rel_l2(u, one) <= 2e-14
+    for devs in ((0, 0, 0), (0,)):                        # one device: the handle still keeps the targets Morton-sorted (no per-call sort)
+        op = sctl_amd.DirectOp("Laplace3D-FxU", np.float64, devices=devs)
+        op.set_targets(xt)
+        op.set_sources(xs)
+        u = np.full(n, 0.5)
+        op.eval(f, u, accumulate=True)
+        assert rel_l2(u - 0.5, one) <= 1e-13
+        op.eval(f, u, accumulate=False)                  # EvalDirect: overwrite
+        assert rel_l2(u, one) <= 2e-14
+        op.eval(f, u, accumulate=False, digits=10)       # the unnormalised Newton step on the pre-sorted centred path
+        assert rel_l2(u, one) <= 1e-13
     three32 = sctl_amd.eval_host("Laplace3D-FxU", xt.astype(np.float32), xs.astype(np.float32), None, f.astype(np.float32), devices=[0, 0, 0])
     assert rel_l2(three32[sel].astype(np.float64), ref) <= 1e-4
