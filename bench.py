@@ -253,9 +253,11 @@ def main():
         if world == 1 and args.digits < 0 and dtype == "f64":
             # Informational, outside the timed region and not part of `value`: the same workload at the accuracy the reference's
             # own callers ask for — ParticleFMM defaults to 10 digits (fmm-wrapper.txx:204), BoundaryIntegralOp to tol 1e-10 (:500).
+            full = op.eval_slab(r_trg, r_src, n_src, v_src).clone()          # the full-precision result, to measure the 10-digit one against
             op10 = ShardedDirectSum(kernel, ctx=ctx, digits=10)
             op10.eval_slab(r_trg, r_src, n_src, v_src, out_slab)
             torch.cuda.synchronize()
+            rel10 = float((out_slab - full).norm() / full.norm())
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(2):
@@ -264,7 +266,8 @@ def main():
             torch.cuda.synchronize()
             ms10 = e0.elapsed_time(e1) / 2
             line["at_reference_callers_accuracy"] = {"digits": 10, "ms_per_step": ms10, "value": pairs_per_step / (ms10 * 1e-3),
-                                                     "frac": pairs_per_step * fpp / (ms10 * 1e-3) / 1e12 / peak}
+                                                     "frac": pairs_per_step * fpp / (ms10 * 1e-3) / 1e12 / peak,
+                                                     "rel_l2_vs_full_precision": rel10}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(kernel, N, dtype)
