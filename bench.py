@@ -116,7 +116,7 @@ def bench_near(args):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "near-field operator: %d elements, blocks %d x %d (Stokes-like), %.2f GB of K_near resident in HBM, %d targets" %
                                    (nelem, nds * k0, near * k1, op.operator_bytes / 1e9, ntrg), "workgroups": op.workgroups},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": read_traffic("near_apply"),
                          "kernel_ms": k_ms, "note": "algorithmic bytes = sizeof(K_near): 8 B per operator entry, read once per application"}}
     if not args.no_cpu_baseline:
         sample = 256                                           # elements; numpy's BLAS GEMV per element, as Matrix::GEMM at :1101
