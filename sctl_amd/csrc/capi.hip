@@ -302,7 +302,8 @@ int eval_host_slab(const KernelEntry& k, int real, int64_t t0, int64_t t1, int64
   const size_t rs = (real == SCTL_AMD_F64) ? 8 : 4;
   const int64_t Nt = t1 - t0;
   if (Nt <= 0 || Ns <= 0) return SCTL_AMD_OK;
-  HIP_TRY(hipSetDevice(device));
+  DeviceScope dev_scope_1(device);
+  HIP_TRY(dev_scope_1.err);
   // Stream, device buffers and pinned staging are kept per (calling thread, device) between calls: at 2^14 points the
   // five hipMalloc/hipFree pairs and the stream creation cost 2.9 of the 3.1 ms a call took.  Anything above 64 MB is
   // released again when the call returns.
@@ -554,7 +555,8 @@ int sctl_amd_kernel_matrix_host(int kernel, int real, int64_t Nt, int64_t Ns, co
   if (device < 0 || device >= avail) return fail(SCTL_AMD_ERR_NO_DEVICE, "device index out of range");
   if (Nt == 0 || Ns == 0) return SCTL_AMD_OK;
   const size_t rs = (real == SCTL_AMD_F64) ? 8 : 4;
-  HIP_TRY(hipSetDevice(device));
+  DeviceScope dev_scope_2(device);
+  HIP_TRY(dev_scope_2.err);
   StreamGuard st;
   HIP_TRY(hipStreamCreateWithFlags(&st.s, hipStreamNonBlocking));
   DevBuf dxt, dxs, dxn, dm;
@@ -603,7 +605,8 @@ int sctl_amd_kernel_matrix_batch_host(int kernel, int real, int64_t nbatch, cons
   if (tiles.empty()) return SCTL_AMD_OK;
   if (tiles.size() > 0x7fffffffu) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "too many tiles for one launch");
   const size_t rs = (real == SCTL_AMD_F64) ? 8 : 4;
-  HIP_TRY(hipSetDevice(device));
+  DeviceScope dev_scope_3(device);
+  HIP_TRY(dev_scope_3.err);
   HostSlot& hs = host_slot(device);
   if (!hs.st.s) HIP_TRY(hipStreamCreateWithFlags(&hs.st.s, hipStreamNonBlocking));
   struct Release { HostSlot& h; ~Release() { h.trim((size_t)64 << 20); } } release{hs};
@@ -644,6 +647,7 @@ int sctl_amd_op_create(int kernel, int real, const int* devices, int n_devices, 
   if (!out || n_devices <= 0) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "null handle pointer or no devices");
   const int avail = device_count_quiet();
   if (avail <= 0) return fail(SCTL_AMD_ERR_NO_DEVICE, "no HIP device: libsctl_amd has no CPU fallback");
+  RestoreDevice restore;
   sctl_amd_op* op = new sctl_amd_op;
   op->k = k; op->real = real;
   op->devs.resize(n_devices);
@@ -662,6 +666,7 @@ int sctl_amd_op_create(int kernel, int real, const int* devices, int n_devices, 
 
 void sctl_amd_op_destroy(sctl_amd_op* op) {
   if (!op) return;
+  RestoreDevice restore;
   const int avail = device_count_quiet();
   for (OpDevice& d : op->devs) {
     if (d.device < 0 || d.device >= avail || !d.st) continue;   // never initialised (create failed on this entry)
@@ -694,7 +699,8 @@ int sctl_amd_op_set_targets(sctl_amd_op* op, int64_t Nt, const void* r_trg) {
   const char* src = sorted.empty() ? (const char*)r_trg : sorted.data();
   return op_for_each_device(op, [&](OpDevice& d) -> int {
     const size_t bytes = (size_t)(d.t1 - d.t0) * 3 * rs;
-    HIP_TRY(hipSetDevice(d.device));
+    DeviceScope dev_scope_4(d.device);
+    HIP_TRY(dev_scope_4.err);
     HIP_TRY(grow(&d.xt, &d.cap_xt, bytes));
     HIP_TRY(d.stage.reserve(pad256(bytes)));
     HIP_TRY(upload(d.xt, src + (size_t)d.t0 * 3 * rs, bytes, d.stage, d.st));
@@ -710,7 +716,8 @@ int sctl_amd_op_set_sources(sctl_amd_op* op, int64_t Ns, const void* r_src, cons
   op->Ns = Ns;
   op->have_weights = false;       // weights belong to a source set
   return op_for_each_device(op, [&](OpDevice& d) -> int {
-    HIP_TRY(hipSetDevice(d.device));
+    DeviceScope dev_scope_5(d.device);
+    HIP_TRY(dev_scope_5.err);
     HIP_TRY(grow(&d.xs, &d.cap_xs, (size_t)Ns * 3 * rs));
     HIP_TRY(grow(&d.xn, &d.cap_xn, (size_t)Ns * op->k->nd * rs));
     HIP_TRY(d.stage.reserve(pad256((size_t)Ns * 3 * rs) + pad256((size_t)Ns * op->k->nd * rs)));
@@ -727,7 +734,8 @@ int sctl_amd_op_set_source_weights(sctl_amd_op* op, const void* wts) {
   const size_t rs = (op->real == SCTL_AMD_F64) ? 8 : 4;
   const int64_t Ns = op->Ns;
   const int rc = op_for_each_device(op, [&](OpDevice& d) -> int {
-    HIP_TRY(hipSetDevice(d.device));
+    DeviceScope dev_scope_6(d.device);
+    HIP_TRY(dev_scope_6.err);
     HIP_TRY(grow(&d.w, &d.cap_w, (size_t)Ns * rs));
     HIP_TRY(d.stage.reserve(pad256((size_t)Ns * rs)));
     HIP_TRY(upload(d.w, wts, (size_t)Ns * rs, d.stage, d.st));
@@ -751,7 +759,8 @@ int sctl_amd_op_set_target_normals(sctl_amd_op* op, const void* n_trg) {
   const char* src = sorted.empty() ? (const char*)n_trg : sorted.data();
   const int rc = op_for_each_device(op, [&](OpDevice& d) -> int {
     const size_t bytes = (size_t)(d.t1 - d.t0) * 3 * rs;
-    HIP_TRY(hipSetDevice(d.device));
+    DeviceScope dev_scope_7(d.device);
+    HIP_TRY(dev_scope_7.err);
     HIP_TRY(grow(&d.nt, &d.cap_nt, bytes));
     HIP_TRY(d.stage.reserve(pad256(bytes)));
     HIP_TRY(upload(d.nt, src + (size_t)d.t0 * 3 * rs, bytes, d.stage, d.st));
@@ -774,7 +783,8 @@ int sctl_amd_op_eval(sctl_amd_op* op, const void* v_src, void* v_trg, int accumu
     const int64_t nt = d.t1 - d.t0;
     const size_t vbytes = (size_t)nt * k.k1 * rs;
     if (nt == 0) return SCTL_AMD_OK;
-    HIP_TRY(hipSetDevice(d.device));
+    DeviceScope dev_scope_8(d.device);
+    HIP_TRY(dev_scope_8.err);
     HIP_TRY(grow(&d.f, &d.cap_f, (size_t)Ns * k.k0 * rs));
     HIP_TRY(grow(&d.v, &d.cap_v, vbytes));
     HIP_TRY(d.stage.reserve(pad256((size_t)Ns * k.k0 * rs) + pad256(vbytes)));

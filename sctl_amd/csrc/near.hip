@@ -3,6 +3,7 @@
 // (boundary_integral.txx:1092-1102), the permutation by near_scatter_index (:1129) and the per-target accumulation
 // (:1131-1140).  HBM-bound: every byte of K_near is read exactly once per application and nothing else is of that order.
 #include "../../include/sctl_amd.h"
+#include "workspace.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -205,7 +206,8 @@ int sctl_amd_near_create(int real, int device, int64_t Nelem, int src_dim, int t
   std::unique_ptr<sctl_amd_near> h(new sctl_amd_near);
   h->real = real; h->device = device; h->k0 = src_dim; h->k1 = trg_dim;
   h->nelem = Nelem; h->ntrg = Ntrg; h->n_near = n_near; h->f_len = f_len; h->k_len = k_len * src_dim * trg_dim; h->nwork = (int64_t)work.size(); h->n_wide = n_wide; h->n_narrow = n_narrow;
-  NEAR_TRY(hipSetDevice(device));
+  DeviceScope dev_scope_1(device);
+  NEAR_TRY(dev_scope_1.err);
   NEAR_TRY(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
   { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) h->cus = n; }
   NEAR_TRY(h->K.alloc((size_t)h->k_len * rs));
@@ -243,7 +245,8 @@ int sctl_amd_near_apply_host(sctl_amd_near* h, const void* F, void* U) {
   if (h->n_near == 0 || h->ntrg == 0) return SCTL_AMD_OK;
   const size_t rs = (h->real == SCTL_AMD_F64) ? 8 : 4;
   const size_t bf = (size_t)h->f_len * rs, bu = (size_t)h->ntrg * h->k1 * rs;
-  NEAR_TRY(hipSetDevice(h->device));
+  DeviceScope dev_scope_2(h->device);
+  NEAR_TRY(dev_scope_2.err);
   char* sf = (char*)h->stage.p;
   char* su = sf + ((bf + 255) & ~(size_t)255);
   std::memcpy(sf, F, bf);                                  // pinned staging: see capi.hip PinnedBuf
@@ -272,7 +275,7 @@ int sctl_amd_near_info(const sctl_amd_near* h, int64_t* density_len, int64_t* po
 
 void sctl_amd_near_destroy(sctl_amd_near* h) {
   if (!h) return;
-  (void)hipSetDevice(h->device);
+  DeviceScope scope(h->device);
   delete h;
 }
 

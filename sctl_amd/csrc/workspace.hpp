@@ -24,6 +24,28 @@ hipError_t workspace_acquire(hipStream_t st, size_t bytes, void** base);
 void workspace_forget(hipStream_t st);
 void workspace_release_all();
 
+// The host-pointer entries select a device for the duration of a call and put the caller's current device back (a caller that
+// also drives torch or its own HIP code on another device must not find it changed behind its back).
+struct DeviceScope {
+  int prev = -1;
+  hipError_t err;
+  explicit DeviceScope(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
+    err = hipSetDevice(device);
+  }
+  ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+  DeviceScope(const DeviceScope&) = delete;
+  DeviceScope& operator=(const DeviceScope&) = delete;
+};
+
+struct RestoreDevice {   // for functions that visit several devices
+  int prev = -1;
+  RestoreDevice() { if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; } }
+  ~RestoreDevice() { if (prev >= 0) (void)hipSetDevice(prev); }
+  RestoreDevice(const RestoreDevice&) = delete;
+  RestoreDevice& operator=(const RestoreDevice&) = delete;
+};
+
 struct Carver {   // 256-byte aligned slices of an acquired block
   char* base;
   size_t off = 0;

@@ -366,3 +366,23 @@ def test_operator_handle_applies_weights_and_target_normals_on_the_device(O, dev
         lap = sctl_amd.DirectOp("Laplace3D-FxU")
         lap.set_targets(xt)
         lap.set_target_normals(ntrg)
+
+
+def test_host_entries_leave_the_callers_current_device_alone(O):
+    """Host-pointer entries pick their device for the duration of the call only: a caller's HIP state (here torch's) is unchanged.
+    On a one-GPU box the check is that nothing breaks and torch still computes on its device afterwards."""
+    import torch
+    torch.cuda.set_device(0)
+    before = torch.cuda.current_device()
+    rng = np.random.default_rng(1)
+    info = sctl_amd.kernel_info("Laplace3D-DxU")
+    xt, xs, xn, f = _rng_inputs(rng, 500, 700, info, np.float64)
+    u = sctl_amd.eval_host("Laplace3D-DxU", xt, xs, xn, f)
+    op = sctl_amd.DirectOp("Laplace3D-DxU")
+    op.set_targets(xt); op.set_sources(xs, xn)
+    u2 = op.eval(f)
+    op.close()
+    sctl_amd.kernel_matrix_host("Laplace3D-DxU", xt[:30].copy(), xs[:60].copy(), xn[:60].copy())
+    assert torch.cuda.current_device() == before
+    assert float(torch.ones(8, device="cuda").sum()) == 8.0
+    assert rel_l2(u, u2) <= 1e-14
