@@ -134,6 +134,24 @@ def bench_near(args):
     print(json.dumps(line), flush=True)
 
 
+def self_launch(n_gpus, argv):
+    """`python bench.py --gpus N` with N > 1 and no rank environment: start the N ranks ourselves, one process per GPU, the way the
+    driver's own multi-GPU command does (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...).
+    Decided BEFORE anything touches the GPU: this parent never imports torch or loads libsctl_amd.so, it only waits for the children
+    (a plain child process, never an exec) and hands their exit code on.  Rank 0's JSON line goes straight to our stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:                      # a free rendezvous port on the loopback interface
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this platform
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -143,8 +161,12 @@ def main():
     ap.add_argument("--digits", type=int, default=-1, help="accuracy request; -1 = full precision (the reference default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
     if args.workload == "near_apply":
         return bench_near(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -155,7 +177,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (the launcher's rank count and --gpus must agree)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: sctl_amd has no CPU path to measure")
     # Rehearsal switch for a ONE-GPU box only: all ranks share device 0 and talk over gloo (RCCL refuses two ranks on one
@@ -163,6 +185,8 @@ def main():
     rehearsal = os.environ.get("SCTL_AMD_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
+    elif torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: --gpus %d but only %d GPU(s) are visible (one rank per GPU)" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -207,6 +231,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    op.set_targets(r_trg)            # the Morton order of the targets is set-up (cached per target set), like SetTrgCoord: never timed
     for _ in range(args.warmup):
         step(False)
     fence()

@@ -167,25 +167,20 @@ template <class Real, class Kernel> class BoundaryIntegralOp {
     const Long Nsrc = X_far.Dim() / COORD_DIM;
     const Long Ntrg = Xtrg.Dim() / COORD_DIM;
     SCTL_AMD_ASSERT(F.Dim() == Dim(0));
-    {  // F_far = density at the far-field nodes; the quadrature weights are applied on the device (:1040-1052)
-      if (F_far.Dim() != Nsrc * KDIM0) F_far.ReInit(Nsrc * KDIM0);
-      const Long Nlst = (Long)elem_lst_name.size();
-      for (Long i = 0; i < Nlst; i++) {
-        const Long elem_idx0 = elem_lst_dsp[i], elem_idx1 = elem_lst_dsp[i] + elem_lst_cnt[i];
-        const Long offset0 = (!elem_lst_cnt[i] ? 0 : elem_nds_dsp[elem_idx0]);
-        const Long offset1 = (!elem_lst_cnt[i] ? 0 : elem_nds_dsp[elem_idx1 - 1] + elem_nds_cnt[elem_idx1 - 1]);
-        const Vector<Real> F_((offset1 - offset0) * KDIM0, (Iterator<Real>)F.begin() + offset0 * KDIM0, false);
-        const Long offset0_far = (!elem_lst_cnt[i] ? 0 : elem_nds_dsp_far[elem_idx0]);
-        const Long offset1_far = (!elem_lst_cnt[i] ? 0 : elem_nds_dsp_far[elem_idx1 - 1] + elem_nds_cnt_far[elem_idx1 - 1]);
-        Vector<Real> F_far_((offset1_far - offset0_far) * KDIM0, F_far.begin() + offset0_far * KDIM0, false);
-        elem_lst_map.at(elem_lst_name[i])->GetFarFieldDensity(F_far_, F_);
-        if (F_far_.Dim()) {
-          SCTL_AMD_ASSERT(F_far_.begin() == F_far.begin() + offset0_far * KDIM0);   // filled in place, not reallocated
-        } else {                                                                     // "same nodes": the density as it is
-          SCTL_AMD_ASSERT(offset1_far - offset0_far == offset1 - offset0);
-          for (Long j = offset0_far; j < offset1_far; j++)
-            for (Long k = 0; k < KDIM0; k++) F_far[j * KDIM0 + k] = F_[(j - offset0_far) * KDIM0 + k];
-        }
+    // Density at the far-field quadrature nodes, one element list at a time (each list owns a contiguous run of surface nodes and
+    // of far-field nodes); the quadrature weights are NOT applied here: they live on the device (boundary_integral.txx:1040-1052).
+    if (F_far.Dim() != Nsrc * KDIM0) F_far.ReInit(Nsrc * KDIM0);
+    for (size_t lst = 0; lst < elem_lst_name.size(); lst++) {
+      const NodeRange surf = ListNodes(lst, elem_nds_cnt, elem_nds_dsp), far = ListNodes(lst, elem_nds_cnt_far, elem_nds_dsp_far);
+      const Vector<Real> f_in((surf.end - surf.begin) * KDIM0, (Iterator<Real>)F.begin() + surf.begin * KDIM0, false);
+      Real* const dst = F_far.begin() + far.begin * KDIM0;
+      Vector<Real> f_out((far.end - far.begin) * KDIM0, dst, false);
+      elem_lst_map.at(elem_lst_name[lst])->GetFarFieldDensity(f_out, f_in);
+      if (f_out.Dim() == 0) {   // the list's answer for "far-field nodes are the surface nodes": the density passes through
+        SCTL_AMD_ASSERT(far.end - far.begin == surf.end - surf.begin);
+        std::copy(f_in.begin(), f_in.begin() + f_in.Dim(), dst);
+      } else {
+        SCTL_AMD_ASSERT(f_out.begin() == dst);   // written into the view, not into a reallocated vector
       }
     }
     const Integer KDIM1_ = (trg_normal_dot_prod_ ? KDIM1 / COORD_DIM : KDIM1);
@@ -247,7 +242,9 @@ template <class Real, class Kernel> class BoundaryIntegralOp {
         const Vector<Real> Xn_(trg_normal_dot_prod_ ? nt * COORD_DIM : 0, trg_normal_dot_prod_ ? Xn_trg_near.begin() + near_elem_dsp[e] * COORD_DIM : nullptr, false);
         const Vector<Real> F_(src_dof, (Iterator<Real>)F.begin() + elem_nds_dsp[e] * KDIM0, false);
         Vector<Real> U_(nt * KDIM1_, U_near.begin() + near_elem_dsp[e] * KDIM1_, false);
-        elem_data_map.at(elem_lst_name[i]).EvalNearInterac(U_, F_, Xt_, Xn_, ker_, tol_, j, elem_lst);
+        // the reference hands EvalNearInterac the GLOBAL element index (boundary_integral.txx:1122), unlike NearInterac, which gets
+        // the list-local one (:925): kept, so that an element list written against the reference behaves the same here
+        elem_data_map.at(elem_lst_name[i]).EvalNearInterac(U_, F_, Xt_, Xn_, ker_, tol_, e, elem_lst);
       }
     }
     for (Long i = 0; i < Ntrg; i++)
@@ -275,6 +272,14 @@ template <class Real, class Kernel> class BoundaryIntegralOp {
       for (Long i = 0; i < p.Dim(); i++) out[off + i] = p[i];
       off += p.Dim();
     }
+  }
+  // nodes [begin, end) owned by element list `lst` in a per-element (count, displacement) layout; empty lists own nothing
+  struct NodeRange { Long begin, end; };
+  NodeRange ListNodes(size_t lst, const Vector<Long>& cnt, const Vector<Long>& dsp) const {
+    const Long n = elem_lst_cnt[(Long)lst];
+    if (n == 0) return NodeRange{0, 0};
+    const Long first = elem_lst_dsp[(Long)lst], last = first + n - 1;
+    return NodeRange{dsp[first], dsp[last] + cnt[last]};
   }
   static void scan(const Vector<Long>& cnt, Vector<Long>& dsp) {   // exclusive prefix sum (omp_par::scan in the reference)
     dsp.ReInit(cnt.Dim());

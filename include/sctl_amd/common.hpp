@@ -28,32 +28,30 @@ template <typename ValueType> inline ConstIterator<ValueType> Ptr2ConstItr(const
 
 }  // namespace sctl_amd
 
-#define SCTL_AMD_ERROR(msg)                                     \
-  do {                                                          \
-    fprintf(stderr, "\n\033[1;31mError:\033[0m %s\n", (msg));   \
-    abort();                                                    \
-  } while (0)
+// Error convention of this surface, the reference's (no return codes, no exceptions: report on stderr, then abort): one
+// noreturn function does the reporting; the macros only capture the call site.
+namespace sctl_amd {
+namespace detail {
+[[noreturn]] inline void fatal(const char* file, int line, const char* func, const char* what, const char* detail_text) {
+  std::fprintf(stderr, "\nsctl_amd fatal error: %s%s%s\n    at %s:%d (%s)\n", what, detail_text ? ": " : "", detail_text ? detail_text : "", file, line, func);
+  std::fflush(stderr);
+  std::abort();
+}
+}  // namespace detail
+}  // namespace sctl_amd
 
-#define SCTL_AMD_ASSERT(cond)                                                                                    \
-  do {                                                                                                           \
-    if (!(cond)) {                                                                                               \
-      fprintf(stderr, "\n%s:%d: %s: Assertion `%s' failed.\n", __FILE__, __LINE__, __PRETTY_FUNCTION__, #cond);  \
-      abort();                                                                                                   \
-    }                                                                                                            \
-  } while (0)
-
-#define SCTL_AMD_ASSERT_MSG(cond, msg) \
-  do {                                 \
-    if (!(cond)) SCTL_AMD_ERROR(msg);  \
-  } while (0)
+#define SCTL_AMD_ERROR(msg) ::sctl_amd::detail::fatal(__FILE__, __LINE__, __func__, (msg), nullptr)
+#define SCTL_AMD_ASSERT(cond) ((cond) ? (void)0 : ::sctl_amd::detail::fatal(__FILE__, __LINE__, __func__, "requirement not met", #cond))
+#define SCTL_AMD_ASSERT_MSG(cond, msg) ((cond) ? (void)0 : ::sctl_amd::detail::fatal(__FILE__, __LINE__, __func__, (msg), #cond))
 
 namespace sctl_amd {
 
 // Status of a C-ABI call -> the reference's convention: print and abort (common.hpp:48-70).
 inline void CheckStatus(int rc, const char* what) {
   if (rc != SCTL_AMD_OK) {
-    fprintf(stderr, "\n\033[1;31mError:\033[0m %s failed (status %d): %s\n", what, rc, sctl_amd_last_error());
-    abort();
+    char text[64];
+    std::snprintf(text, sizeof text, "%s failed with status %d", what, rc);
+    detail::fatal(__FILE__, __LINE__, __func__, text, sctl_amd_last_error());
   }
 }
 

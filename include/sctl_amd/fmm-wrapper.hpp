@@ -43,57 +43,53 @@ template <class Real, Integer DIM = 3> class ParticleFMM {
   void SetComm(const Comm& comm) { comm_ = comm; }
   void SetAccuracy(Integer digits) { digits_ = digits; }
 
+  // The far-field (multipole / local) kernels only fix dimensions here — there is no FMM tree in this library — but the
+  // consistency rules of the reference are kept, because Eval() refuses to run on an inconsistent set (fmm-wrapper.txx:568-604).
   template <class KerM2M, class KerM2L, class KerL2L> void SetKernels(const KerM2M& ker_m2m, const KerM2L& ker_m2l, const KerL2L& ker_l2l) {
-    fmm_ker_.dim_mul_eq = ker_m2m.SrcDim();
-    fmm_ker_.dim_mul_ch = ker_m2m.TrgDim();
-    fmm_ker_.dim_loc_eq = ker_l2l.SrcDim();
-    fmm_ker_.dim_loc_ch = ker_l2l.TrgDim();
-    SCTL_AMD_ASSERT(ker_m2m.CoordDim() == DIM);
-    SCTL_AMD_ASSERT(ker_m2l.CoordDim() == DIM);
-    SCTL_AMD_ASSERT(ker_l2l.CoordDim() == DIM);
-    SCTL_AMD_ASSERT(ker_m2l.SrcDim() == fmm_ker_.dim_mul_eq);
-    SCTL_AMD_ASSERT(ker_m2l.TrgDim() == fmm_ker_.dim_loc_ch);
+    RequireCoordDim(ker_m2m, "M2M kernel");
+    RequireCoordDim(ker_m2l, "M2L kernel");
+    RequireCoordDim(ker_l2l, "L2L kernel");
+    fmm_ker_ = FMMKernels{ker_m2m.TrgDim(), ker_m2m.SrcDim(), ker_l2l.TrgDim(), ker_l2l.SrcDim()};
+    Require(ker_m2l.SrcDim() == fmm_ker_.dim_mul_eq && ker_m2l.TrgDim() == fmm_ker_.dim_loc_ch,
+            "SetKernels: the M2L kernel must map multipole-equivalent densities to local-check potentials");
     have_fmm_ker_ = true;
   }
 
   template <class KerS2M, class KerS2L> void AddSrc(const std::string& name, const KerS2M& ker_s2m, const KerS2L& ker_s2l) {
-    SCTL_AMD_ASSERT_MSG(src_map_.find(name) == src_map_.end(), "Source name already exists.");
+    Require(!src_map_.count(name), "AddSrc: a source type called '" + name + "' is already registered");
+    RequireCoordDim(ker_s2m, "S2M kernel");
+    RequireCoordDim(ker_s2l, "S2L kernel");
+    Require(ker_s2l.SrcDim() == ker_s2m.SrcDim() && ker_s2l.NormalDim() == ker_s2m.NormalDim(),
+            "AddSrc('" + name + "'): the S2M and S2L kernels disagree on the density or normal dimension");
     SrcData& data = src_map_[name];
     data.dim_src = ker_s2m.SrcDim();
+    data.dim_normal = ker_s2m.NormalDim();
     data.dim_mul_ch = ker_s2m.TrgDim();
     data.dim_loc_ch = ker_s2l.TrgDim();
-    data.dim_normal = ker_s2m.NormalDim();
-    SCTL_AMD_ASSERT(ker_s2m.CoordDim() == DIM);
-    SCTL_AMD_ASSERT(ker_s2l.CoordDim() == DIM);
-    SCTL_AMD_ASSERT(ker_s2l.SrcDim() == data.dim_src);
-    SCTL_AMD_ASSERT(ker_s2l.NormalDim() == data.dim_normal);
   }
 
   template <class KerM2T, class KerL2T> void AddTrg(const std::string& name, const KerM2T& ker_m2t, const KerL2T& ker_l2t) {
-    SCTL_AMD_ASSERT_MSG(trg_map_.find(name) == trg_map_.end(), "Target name already exists.");
+    Require(!trg_map_.count(name), "AddTrg: a target type called '" + name + "' is already registered");
+    RequireCoordDim(ker_m2t, "M2T kernel");
+    RequireCoordDim(ker_l2t, "L2T kernel");
+    Require(ker_m2t.TrgDim() == ker_l2t.TrgDim(), "AddTrg('" + name + "'): the M2T and L2T kernels disagree on the potential dimension");
     TrgData& data = trg_map_[name];
     data.dim_trg = ker_l2t.TrgDim();
     data.dim_mul_eq = ker_m2t.SrcDim();
     data.dim_loc_eq = ker_l2t.SrcDim();
-    SCTL_AMD_ASSERT(ker_m2t.CoordDim() == DIM);
-    SCTL_AMD_ASSERT(ker_l2t.CoordDim() == DIM);
-    SCTL_AMD_ASSERT(ker_m2t.TrgDim() == data.dim_trg);
   }
 
   template <class KerS2T> void SetKernelS2T(const std::string& src_name, const std::string& trg_name, const KerS2T& ker_s2t) {
-    SCTL_AMD_ASSERT_MSG(src_map_.find(src_name) != src_map_.end(), "Source name does not exists.");
-    SCTL_AMD_ASSERT_MSG(trg_map_.find(trg_name) != trg_map_.end(), "Target name does not exists.");
-    S2TData& data = s2t_map_[std::make_pair(src_name, trg_name)];   // replaces an existing entry
+    Require(src_map_.count(src_name), "SetKernelS2T: unknown source type '" + src_name + "'");
+    Require(trg_map_.count(trg_name), "SetKernelS2T: unknown target type '" + trg_name + "'");
+    RequireCoordDim(ker_s2t, "S2T kernel");
+    S2TData& data = s2t_map_[std::make_pair(src_name, trg_name)];   // a second call for the same pair replaces the kernel
     data.Release();
     data.dim_src = ker_s2t.SrcDim();
     data.dim_trg = ker_s2t.TrgDim();
     data.dim_normal = ker_s2t.NormalDim();
-    SCTL_AMD_ASSERT(ker_s2t.CoordDim() == DIM);
     data.kernel_id = KerS2T::DeviceKernelId();
-    if (data.kernel_id < 0) {
-      const std::string msg = "S2T kernel '" + KerS2T::Name() + "' is not implemented in libsctl_amd.so (no host fallback in sctl_amd)";
-      SCTL_AMD_ERROR(msg.c_str());
-    }
+    Require(data.kernel_id >= 0, "S2T kernel '" + KerS2T::Name() + "' is not implemented in libsctl_amd.so (no host fallback in sctl_amd)");
     int ctx_bytes = 0;
     CheckStatus(sctl_amd_kernel_info(data.kernel_id, nullptr, nullptr, nullptr, nullptr, nullptr, &ctx_bytes), "sctl_amd_kernel_info");
     data.ctx.assign((const char*)ker_s2t.GetCtxPtr(), (const char*)ker_s2t.GetCtxPtr() + (ker_s2t.GetCtxPtr() ? ctx_bytes : 0));
@@ -101,34 +97,24 @@ template <class Real, Integer DIM = 3> class ParticleFMM {
   }
 
   void DeleteSrc(const std::string& name) {
-    SCTL_AMD_ASSERT_MSG(src_map_.find(name) != src_map_.end(), "Source name does not exist.");
-    src_map_.erase(name);
-    for (auto it = s2t_map_.begin(); it != s2t_map_.end();) {
-      if (it->first.first == name) { it->second.Release(); it = s2t_map_.erase(it); } else ++it;
-    }
+    Require(src_map_.erase(name) == 1, "DeleteSrc: unknown source type '" + name + "'");
+    DropPairs([&](const PairKey& k) { return k.first == name; });
   }
   void DeleteTrg(const std::string& name) {
-    SCTL_AMD_ASSERT_MSG(trg_map_.find(name) != trg_map_.end(), "Target name does not exist.");
-    trg_map_.erase(name);
-    for (auto it = s2t_map_.begin(); it != s2t_map_.end();) {
-      if (it->first.second == name) { it->second.Release(); it = s2t_map_.erase(it); } else ++it;
-    }
+    Require(trg_map_.erase(name) == 1, "DeleteTrg: unknown target type '" + name + "'");
+    DropPairs([&](const PairKey& k) { return k.second == name; });
   }
 
+  // The object keeps its own copies (fmm-wrapper.txx:444-479); new coordinates mark the device-resident copies stale.
   void SetSrcCoord(const std::string& name, const Vector<Real>& src_coord, const Vector<Real>& src_normal = Vector<Real>()) {
-    SCTL_AMD_ASSERT_MSG(src_map_.find(name) != src_map_.end(), "Target name does not exist.");
-    SrcData& data = src_map_[name];
+    SrcData& data = Find(src_map_, name, "SetSrcCoord: unknown source type");
     data.X = src_coord;
     data.Xn = src_normal;
-    for (auto& it : s2t_map_) if (it.first.first == name) it.second.src_dirty = true;   // re-upload at the next Eval
+    for (auto& it : s2t_map_) if (it.first.first == name) it.second.src_dirty = true;
   }
-  void SetSrcDensity(const std::string& name, const Vector<Real>& src_density) {
-    SCTL_AMD_ASSERT_MSG(src_map_.find(name) != src_map_.end(), "Target name does not exist.");
-    src_map_[name].F = src_density;
-  }
+  void SetSrcDensity(const std::string& name, const Vector<Real>& src_density) { Find(src_map_, name, "SetSrcDensity: unknown source type").F = src_density; }
   void SetTrgCoord(const std::string& name, const Vector<Real>& trg_coord) {
-    SCTL_AMD_ASSERT_MSG(trg_map_.find(name) != trg_map_.end(), "Target name does not exist.");
-    trg_map_[name].X = trg_coord;
+    Find(trg_map_, name, "SetTrgCoord: unknown target type").X = trg_coord;
     for (auto& it : s2t_map_) if (it.first.second == name) it.second.trg_dirty = true;
   }
 
@@ -138,7 +124,7 @@ template <class Real, Integer DIM = 3> class ParticleFMM {
   }
 
   void EvalDirect(Vector<Real>& U, const std::string& trg_name) const {
-    SCTL_AMD_ASSERT_MSG(trg_map_.find(trg_name) != trg_map_.end(), "Target name does not exist.");
+    Require(trg_map_.count(trg_name), "EvalDirect: unknown target type '" + trg_name + "'");
     const TrgData& trg_data = trg_map_.at(trg_name);
     const Integer TrgDim = trg_data.dim_trg;
     const Vector<Real>& Xt = trg_data.X;
@@ -150,7 +136,7 @@ template <class Real, Integer DIM = 3> class ParticleFMM {
     for (const auto& it : s2t_map_) {
       if (it.first.second != trg_name) continue;
       const std::string& src_name = it.first.first;
-      SCTL_AMD_ASSERT_MSG(src_map_.find(src_name) != src_map_.end(), "Source name does not exist.");
+      Require(src_map_.count(src_name), "EvalDirect: the source type '" + src_name + "' of an S2T kernel was deleted");
       const SrcData& src_data = src_map_.at(src_name);
       const S2TData& s2t = it.second;
       const Integer SrcDim = src_data.dim_src;
@@ -201,33 +187,50 @@ template <class Real, Integer DIM = 3> class ParticleFMM {
     }
   };
 
-  // fmm-wrapper.txx:568-604
+  typedef std::pair<std::string, std::string> PairKey;   // (source type, target type)
+
+  static void Require(bool ok, const std::string& what) {
+    if (!ok) SCTL_AMD_ERROR(what.c_str());
+  }
+  template <class Ker> static void RequireCoordDim(const Ker& ker, const char* role) {
+    Require(ker.CoordDim() == DIM, std::string(role) + " '" + Ker::Name() + "' is not a " + std::to_string(DIM) + "-dimensional kernel");
+  }
+  template <class Map> static typename Map::mapped_type& Find(Map& m, const std::string& name, const char* what) {
+    auto it = m.find(name);
+    Require(it != m.end(), std::string(what) + " '" + name + "'");
+    return it->second;
+  }
+  template <class Pred> void DropPairs(Pred drop) {
+    for (auto it = s2t_map_.begin(); it != s2t_map_.end();) {
+      if (drop(it->first)) { it->second.Release(); it = s2t_map_.erase(it); } else ++it;
+    }
+  }
+
+  // What Eval() insists on before it runs (the rules of fmm-wrapper.txx:568-604): far-field kernels set, an S2T kernel for EVERY
+  // (source type, target type) pair, and all dimensions consistent between the pair kernels, the types and the far-field kernels.
   void CheckKernelDims() const {
-    SCTL_AMD_ASSERT(have_fmm_ker_);
-    for (const auto& src_it : src_map_)
-      for (const auto& trg_it : trg_map_) {
-        const std::string msg = "S2T kernel for " + src_it.first + "-" + trg_it.first + " was not provided.";
-        SCTL_AMD_ASSERT_MSG(s2t_map_.find(std::make_pair(src_it.first, trg_it.first)) != s2t_map_.end(), msg.c_str());
-      }
+    Require(have_fmm_ker_, "Eval: SetKernels has not been called");
+    for (const auto& src : src_map_)
+      for (const auto& trg : trg_map_)
+        Require(s2t_map_.count(PairKey(src.first, trg.first)), "Eval: no S2T kernel was set for sources '" + src.first + "' and targets '" + trg.first + "'");
     for (const auto& it : s2t_map_) {
-      SCTL_AMD_ASSERT_MSG(src_map_.find(it.first.first) != src_map_.end(), "Source name does not exist.");
-      SCTL_AMD_ASSERT_MSG(trg_map_.find(it.first.second) != trg_map_.end(), "Source name does not exist.");
-      const SrcData& src_data = src_map_.at(it.first.first);
-      const TrgData& trg_data = trg_map_.at(it.first.second);
-      SCTL_AMD_ASSERT(trg_data.dim_trg == it.second.dim_trg);
-      SCTL_AMD_ASSERT(src_data.dim_src == it.second.dim_src);
-      SCTL_AMD_ASSERT(src_data.dim_normal == it.second.dim_normal);
-      SCTL_AMD_ASSERT(src_data.dim_mul_ch == fmm_ker_.dim_mul_ch);
-      SCTL_AMD_ASSERT(src_data.dim_loc_ch == fmm_ker_.dim_loc_ch);
-      SCTL_AMD_ASSERT(trg_data.dim_mul_eq == fmm_ker_.dim_mul_eq);
-      SCTL_AMD_ASSERT(trg_data.dim_loc_eq == fmm_ker_.dim_loc_eq);
+      const std::string pair = "'" + it.first.first + "' -> '" + it.first.second + "'";
+      Require(src_map_.count(it.first.first) && trg_map_.count(it.first.second), "Eval: the S2T kernel " + pair + " refers to a deleted type");
+      const SrcData& src = src_map_.at(it.first.first);
+      const TrgData& trg = trg_map_.at(it.first.second);
+      Require(it.second.dim_src == src.dim_src && it.second.dim_normal == src.dim_normal && it.second.dim_trg == trg.dim_trg,
+              "Eval: the S2T kernel " + pair + " does not fit the dimensions its source and target types were registered with");
+      Require(src.dim_mul_ch == fmm_ker_.dim_mul_ch && src.dim_loc_ch == fmm_ker_.dim_loc_ch,
+              "Eval: source type '" + it.first.first + "' does not fit the far-field kernels (check-potential dimensions)");
+      Require(trg.dim_mul_eq == fmm_ker_.dim_mul_eq && trg.dim_loc_eq == fmm_ker_.dim_loc_eq,
+              "Eval: target type '" + it.first.second + "' does not fit the far-field kernels (equivalent-density dimensions)");
     }
   }
 
   FMMKernels fmm_ker_;
   std::map<std::string, SrcData> src_map_;
   std::map<std::string, TrgData> trg_map_;
-  std::map<std::pair<std::string, std::string>, S2TData> s2t_map_;
+  std::map<PairKey, S2TData> s2t_map_;
   Comm comm_;
   Integer digits_;
   bool have_fmm_ker_;

@@ -210,24 +210,27 @@ def rel_l2(a, b):
 NEAR_INT_ARRAYS = ("elem_nds_cnt", "near_elem_cnt", "K_near_cnt", "near_scatter_index", "near_trg_cnt", "near_trg_dsp")
 
 
-def reference_near(name, xt, xn_trg, xs, xn, wts, f, trg_normal_dot_prod=False, tol=1e-10, nodes_per_elem=4, upsample=1, rad=0.1):
+def reference_near(name, xt, xn_trg, xs, xn, wts, f, trg_normal_dot_prod=False, tol=1e-10, nodes_per_elem=4, upsample=1, rad=0.1, free_nodes=0):
     """The REAL reference's BoundaryIntegralOp on the synthetic PatchElemList of oracle/ref_near_shim.cpp (build container only).
-    Returns u_total (ComputePotential), u_near (ComputeNearInterac alone) and the near-operator arrays SetupNear built."""
+    Returns u_total (ComputePotential), u_near (ComputeNearInterac alone) and the near-operator arrays SetupNear built.
+    free_nodes > 0: TWO element lists — the last `free_nodes` nodes form a second, matrix-free list (sctl_ref_boundary_near2)."""
     path = os.path.join(_HERE, "_ref", "libsctl_ref_near.so")
     lib = C.CDLL(path)
     Ns = xs.size // 3
     Nt = 0 if xt is None else xt.size // 3
     NT = Nt if Nt else Ns
-    nelem = (Ns + nodes_per_elem - 1) // nodes_per_elem
+    ns_a = Ns - free_nodes
+    nelem = (ns_a + nodes_per_elem - 1) // nodes_per_elem + (free_nodes + nodes_per_elem - 1) // nodes_per_elem
     near_cap, k_cap = NT * nelem, NT * nelem * nodes_per_elem * 9
     out = dict(u_total=np.zeros(NT * 9), u_near=np.zeros(NT * 9), K_near=np.zeros(k_cap))
     for k, n in (("elem_nds_cnt", nelem), ("near_elem_cnt", nelem), ("K_near_cnt", nelem), ("near_scatter_index", near_cap), ("near_trg_cnt", NT), ("near_trg_dsp", NT)):
         out[k] = np.zeros(n, dtype=np.int64)
     sizes = np.zeros(8, dtype=np.int64)
-    fn = lib.sctl_ref_boundary_near
-    fn.argtypes = ([C.c_char_p, C.c_int64, C.c_int64] + [C.c_void_p] * 6 + [C.c_int, C.c_double, C.c_int, C.c_int, C.c_double] + [C.c_void_p] * 2 + [C.c_int64] +
-                   [C.c_void_p] * 4 + [C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64])
-    rc = fn(name.encode(), Nt, Ns, _ptr(xt), _ptr(xn_trg), _ptr(xs), _ptr(xn), _ptr(wts), _ptr(f), 1 if trg_normal_dot_prod else 0, tol, nodes_per_elem,
+    fn = lib.sctl_ref_boundary_near2 if free_nodes else lib.sctl_ref_boundary_near
+    fn.argtypes = ([C.c_char_p, C.c_int64, C.c_int64] + ([C.c_int64] if free_nodes else []) + [C.c_void_p] * 6 + [C.c_int, C.c_double, C.c_int, C.c_int, C.c_double] +
+                   [C.c_void_p] * 2 + [C.c_int64] + [C.c_void_p] * 4 + [C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64])
+    sizes_in = (Nt, ns_a, free_nodes) if free_nodes else (Nt, Ns)
+    rc = fn(name.encode(), *sizes_in, _ptr(xt), _ptr(xn_trg), _ptr(xs), _ptr(xn), _ptr(wts), _ptr(f), 1 if trg_normal_dot_prod else 0, tol, nodes_per_elem,
             upsample, rad, _ptr(out["u_total"]), _ptr(out["u_near"]), out["u_total"].size, _ptr(sizes), _ptr(out["elem_nds_cnt"]),
             _ptr(out["near_elem_cnt"]), _ptr(out["K_near_cnt"]), nelem, _ptr(out["near_scatter_index"]), near_cap, _ptr(out["near_trg_cnt"]),
             _ptr(out["near_trg_dsp"]), NT, _ptr(out["K_near"]), k_cap)

@@ -30,6 +30,13 @@ CASES = [
     ("Stokes3D-DxU", 150, 120, 5, 1, 0, 0.20),
     ("Stokes3D-FxT", 100, 90, 3, 2, 1, 0.20),
 ]
+# two element lists in one operator, the second one matrix-free with a near zone: kernel, Nt, Ns (all nodes), nodes of the
+# matrix-free list (the LAST ones), nodes per element, upsampling, dot, far-field distance
+CASES2 = [
+    ("Laplace3D-FxU", 250, 230, 90, 4, 1, 0, 0.18),
+    ("Stokes3D-DxU", 0, 150, 61, 5, 2, 0, 0.20),
+    ("Laplace3D-FxdU", 140, 120, 50, 3, 1, 1, 0.20),
+]
 
 
 def near_inputs(seed, Nt, Ns, k0):
@@ -56,6 +63,17 @@ def main():
         for k, v in r.items():
             arrays["%s/%s" % (key, k)] = v
         cases.append(dict(key=key, kernel=name, Nt=Nt, Ns=Ns, seed=seed, nodes_per_elem=npe, upsample=ups, trg_normal_dot_prod=dot, rad=rad,
+                          near_entries=int(r["near_scatter_index"].size), K_near_len=int(r["K_near"].size)))
+        print(name, cases[-1])
+    for i, (name, Nt, Ns, nfree, npe, ups, dot, rad) in enumerate(CASES2):
+        inf = O.info(name)
+        seed = 800 + i
+        xt, xnt, xs, xn, w, f = near_inputs(seed, Nt, Ns, inf["k0"])
+        r = oracle.reference_near(name, xt if Nt else None, xnt if Nt else None, xs, xn, w, f, bool(dot), 1e-10, npe, ups, rad, free_nodes=nfree)
+        key = "t%d" % i
+        for k, v in r.items():
+            arrays["%s/%s" % (key, k)] = v
+        cases.append(dict(key=key, kernel=name, Nt=Nt, Ns=Ns, seed=seed, nodes_per_elem=npe, upsample=ups, trg_normal_dot_prod=dot, rad=rad, free_nodes=nfree,
                           near_entries=int(r["near_scatter_index"].size), K_near_len=int(r["K_near"].size)))
         print(name, cases[-1])
     out = os.path.join(ROOT, "tests", "golden")

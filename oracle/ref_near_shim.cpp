@@ -121,10 +121,43 @@ template <class Real> class PatchElemList : public sctl::ElementListBase<Real> {
     NearBlock(M, &Xt[0], nt, dot, ker, L, elem_idx);
   }
 
- private:
+ protected:
   Vector<Real> X, Xn, w;
   Long npe, ups;
   Real rad;
+};
+
+// The same patches as a MATRIX-FREE element list (MatrixFree() = true: no K_near block, no direct-part subtraction; the near
+// zone is applied by EvalNearInterac per element, boundary_integral.txx:1104-1125).  Synthetic rule, stated again in
+// tests/cpp/bie_driver.cpp:   u[t][k1] = 0.25 * sum_{j,k0} f[j][k0] * NearBlock(e, x_t)[(j,k0)][k1].
+// The reference hands EvalNearInterac the GLOBAL element index elem_lst_dsp[i] + j (:1122) — unlike NearInterac, which gets
+// the list-local j (:925) — so a list that is not the first one must know where its elements start: `first`.
+template <class Real> class FreePatchElemList : public PatchElemList<Real> {
+ public:
+  FreePatchElemList() : first(0) {}
+  FreePatchElemList(const Vector<Real>& X_, const Vector<Real>& Xn_, const Vector<Real>& w_, Long nodes_per_elem, Long upsample, Real rad_, Long first_global_elem)
+      : PatchElemList<Real>(X_, Xn_, w_, nodes_per_elem, upsample, rad_), first(first_global_elem) {}
+  bool MatrixFree() const override { return true; }
+  template <class Kernel> static void EvalNearInterac(Vector<Real>& u, const Vector<Real>& f, const Vector<Real>& Xt, const Vector<Real>& normal_trg, const Kernel& ker, Real tol, const Long elem_idx, const sctl::ElementListBase<Real>* self) {
+    const FreePatchElemList& L = *dynamic_cast<const FreePatchElemList*>(self);
+    const Long e = elem_idx - L.first, nt = Xt.Dim() / 3;
+    const bool dot = normal_trg.Dim() > 0;
+    const Long K1_ = (nt ? u.Dim() / nt : 0);
+    for (Long t = 0; t < nt; t++) {
+      Real nrm[3] = {0, 0, 0};
+      if (dot) for (int k = 0; k < 3; k++) nrm[k] = normal_trg[t * 3 + k];
+      Matrix<Real> M;
+      PatchElemList<Real>::NearBlock(M, &Xt[t * 3], nrm, dot, ker, L, e);
+      for (Long k1 = 0; k1 < K1_; k1++) {
+        Real s = 0;
+        for (Long r = 0; r < M.Dim(0); r++) s += f[r] * M[r][k1];
+        u[t * K1_ + k1] = (Real)0.25 * s;
+      }
+    }
+  }
+
+ private:
+  Long first;
 };
 }  // namespace ref_ext
 
@@ -170,6 +203,44 @@ int sctl_ref_boundary_near(const char* name, int64_t Nt, int64_t Ns, const doubl
     Vector<Real> U, Un;
     op.ComputePotential(U, F);
     op.ComputeNearInterac(Un, F);          // private in the reference: this file is compiled with -fno-access-control
+    bool ok = put(u_total, u_cap, U) >= 0 && put(u_near, u_cap, Un) >= 0;
+    ok = ok && put<Long>((Long*)elem_nds_cnt, elem_cap, op.elem_nds_cnt) >= 0 && put<Long>((Long*)near_elem_cnt, elem_cap, op.near_elem_cnt) >= 0;
+    ok = ok && put<Long>((Long*)K_near_cnt, elem_cap, op.K_near_cnt) >= 0 && put<Long>((Long*)near_scatter_index, near_cap, op.near_scatter_index) >= 0;
+    ok = ok && put<Long>((Long*)near_trg_cnt, trg_cap, op.near_trg_cnt) >= 0 && put<Long>((Long*)near_trg_dsp, trg_cap, op.near_trg_dsp) >= 0;
+    ok = ok && put(K_near, K_cap, op.K_near) >= 0;
+    sizes[0] = op.near_trg_cnt.Dim(); sizes[1] = op.near_elem_cnt.Dim(); sizes[2] = op.near_scatter_index.Dim(); sizes[3] = op.K_near.Dim(); sizes[4] = U.Dim();
+    return ok ? 0 : -2;
+  });
+}
+
+// Two element lists in one operator: "a_patches" (nodes [0, NsA), precomputed matrices) and "b_free" (nodes [NsA, NsA+NsB),
+// matrix-free) — std::map order puts a_patches first, so b_free's elements start at global index Size(a_patches).
+// Same outputs as sctl_ref_boundary_near.
+int sctl_ref_boundary_near2(const char* name, int64_t Nt, int64_t NsA, int64_t NsB, const double* xt, const double* xn_trg, const double* xs,
+                            const double* xn, const double* wts, const double* f, int trg_normal_dot_prod, double tol, int nodes_per_elem, int upsample,
+                            double rad, double* u_total, double* u_near, int64_t u_cap, int64_t* sizes, int64_t* elem_nds_cnt, int64_t* near_elem_cnt,
+                            int64_t* K_near_cnt, int64_t elem_cap, int64_t* near_scatter_index, int64_t near_cap, int64_t* near_trg_cnt,
+                            int64_t* near_trg_dsp, int64_t trg_cap, double* K_near, int64_t K_cap) {
+  return dispatch(name, [&](auto k) {
+    using K = decltype(k);
+    using Real = double;
+    K ker;
+    BoundaryIntegralOp<Real, K> op(ker, trg_normal_dot_prod != 0, Comm::Self());
+    op.SetAccuracy(tol);
+    const int64_t Ns = NsA + NsB;
+    auto view = [](const double* p, int64_t off, int64_t n) { return Vector<Real>(n, Ptr2Itr<Real>((Real*)p + off, n), false); };
+    ref_ext::PatchElemList<Real> A(view(xs, 0, NsA * 3), view(xn, 0, NsA * 3), view(wts, 0, NsA), nodes_per_elem, upsample, rad);
+    ref_ext::FreePatchElemList<Real> B(view(xs, NsA * 3, NsB * 3), view(xn, NsA * 3, NsB * 3), view(wts, NsA, NsB), nodes_per_elem, upsample, rad, A.Size());
+    op.AddElemList(A, "a_patches");
+    op.AddElemList(B, "b_free");
+    Vector<Real> F(Ns * K::SrcDim(), Ptr2Itr<Real>((Real*)f, Ns * K::SrcDim()), false);
+    if (Nt > 0) {
+      op.SetTargetCoord(Vector<Real>(Nt * 3, Ptr2Itr<Real>((Real*)xt, Nt * 3), false));
+      if (trg_normal_dot_prod) op.SetTargetNormal(Vector<Real>(Nt * 3, Ptr2Itr<Real>((Real*)xn_trg, Nt * 3), false));
+    }
+    Vector<Real> U, Un;
+    op.ComputePotential(U, F);
+    op.ComputeNearInterac(Un, F);
     bool ok = put(u_total, u_cap, U) >= 0 && put(u_near, u_cap, Un) >= 0;
     ok = ok && put<Long>((Long*)elem_nds_cnt, elem_cap, op.elem_nds_cnt) >= 0 && put<Long>((Long*)near_elem_cnt, elem_cap, op.near_elem_cnt) >= 0;
     ok = ok && put<Long>((Long*)K_near_cnt, elem_cap, op.K_near_cnt) >= 0 && put<Long>((Long*)near_scatter_index, near_cap, op.near_scatter_index) >= 0;

@@ -34,7 +34,9 @@ void centered_plan(int64_t Nt, int64_t Ns, int cus, int* T, int* splits, int64_t
   const int64_t want = (int64_t)cus * 16 * 32;
   const int64_t ntile = (Ns + kWaveTile - 1) / kWaveTile;
   int64_t s = (want + wg_x - 1) / wg_x;
-  if (const char* e = std::getenv("SCTL_AMD_EXPERIMENT_SPLITS")) s = std::atoi(e);   // timing experiments only
+#ifdef SCTL_AMD_EXPERIMENTS   // timing experiments only (tools/): never defined for the shipped library
+  if (const char* e = std::getenv("SCTL_AMD_EXPERIMENT_SPLITS")) s = std::atoi(e);
+#endif
   if (s > ntile / 64) s = ntile / 64;      // at least 64 tiles (4096 sources) per split
   if (s > 64) s = 64;
   if (s < 1) s = 1;
@@ -100,7 +102,9 @@ hipError_t eval_centered_t(int64_t Nt, int64_t Ns, const R* xt, const R* xs, con
   a.Nt = Nt; a.Ns = Ns; a.xt = xts; a.xs = xs; a.xn = xn; a.f = f; a.v_trg = outs; a.partial = nullptr;
   a.chunk = chunk; a.scale = scale;
   a.ctx.v[0] = kNearFactor2;
-  if (const char* e = std::getenv("SCTL_AMD_EXPERIMENT_NEAR_FACTOR")) a.ctx.v[0] = std::atof(e);   // timing experiments only
+#ifdef SCTL_AMD_EXPERIMENTS   // timing experiments only (tools/near_factor.py); values below kNearFactor2 void the accuracy bound
+  if (const char* e = std::getenv("SCTL_AMD_EXPERIMENT_NEAR_FACTOR")) a.ctx.v[0] = std::atof(e);
+#endif
   a.partial = partial;
   const dim3 grid((unsigned)((Nt + (int64_t)kWaveBlock * T - 1) / ((int64_t)kWaveBlock * T)), (unsigned)splits);
   if (mode == 0) launch_centered<CP, R, 0>(a, grid, st);

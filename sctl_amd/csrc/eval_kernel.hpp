@@ -40,12 +40,12 @@ template <> struct VecOf<double> { typedef double type __attribute__((ext_vector
 template <> struct VecOf<float> { typedef float type __attribute__((ext_vector_type(4))); static constexpr int N = 4; };
 
 // sources per unrolled loop body: 4-8 independent accumulation chains in flight per lane
-#ifdef SCTL_AMD_EXP_UNROLL   // timing experiments only (tools/)
+#if defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_UNROLL)   // timing experiments only (tools/)
 template <int T, int K1> struct UnrollOf { static constexpr int value = SCTL_AMD_EXP_UNROLL; };
 #else
 template <int T, int K1> struct UnrollOf { static constexpr int value = (T * K1 >= 8) ? 1 : ((T * K1 >= 3) ? 2 : 4); };
 #endif
-#ifdef SCTL_AMD_EXP_WAVES
+#if defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_WAVES)
 #define SCTL_AMD_EVAL_ATTR __attribute__((amdgpu_waves_per_eu(SCTL_AMD_EXP_WAVES, SCTL_AMD_EXP_WAVES)))
 #else
 #define SCTL_AMD_EVAL_ATTR

@@ -67,7 +67,7 @@ class ShardedDirectSum:
         self.compact = compact
         self._hip = local_eval is None
         self.local_eval = local_eval or self._hip_eval
-        self._trg_key, self._perm, self._slab_xt = None, None, None
+        self._trg_ref, self._trg_version, self._perm, self._slab_xt = None, None, None, None
 
     def _hip_eval(self, r_trg_slab, r_src, n_src, v_src, v_out, nt_whole=None):
         return api.eval_device(self.info["id"], r_trg_slab, r_src, n_src, v_src, v_trg=v_out, digits=self.digits, ctx=self.ctx, nt_whole=nt_whole)
@@ -79,12 +79,27 @@ class ShardedDirectSum:
         if not (self.compact and self.world > 1):
             self._perm = None
             return r_trg[t0 * 3:t1 * 3]
-        key = (r_trg.data_ptr(), r_trg.numel(), r_trg._version, r_trg.dtype, r_trg.device)
-        if key != self._trg_key:
-            self._perm = morton_order(r_trg)
-            self._slab_xt = r_trg.view(-1, 3)[self._perm[t0:t1]].contiguous().view(-1)
-            self._trg_key = key
+        # The cache is tied to the tensor OBJECT (kept alive here, so its storage cannot be handed to another tensor) and to its
+        # version counter (in-place writes): a new tensor of the same size at a recycled address never hits it.
+        if r_trg is not self._trg_ref or r_trg._version != self._trg_version:
+            self.set_targets(r_trg)
         return self._slab_xt
+
+    def set_targets(self, r_trg):
+        """(Re)compute the Morton order and this rank's compact slab for a target set — ParticleFMM::SetTrgCoord's role
+        (fmm-wrapper.txx:462-470).  eval()/eval_slab() call it themselves when they see another tensor or a modified one."""
+        Nt = r_trg.numel() // 3
+        t0, t1 = slab_bounds(Nt, self.rank, self.world)
+        if not (self.compact and self.world > 1):
+            self.invalidate()
+            return
+        self._perm = morton_order(r_trg)
+        self._slab_xt = r_trg.view(-1, 3)[self._perm[t0:t1]].contiguous().view(-1)
+        self._trg_ref, self._trg_version = r_trg, r_trg._version
+
+    def invalidate(self):
+        """Forget the cached target order (and the reference to the caller's tensor)."""
+        self._trg_ref, self._trg_version, self._perm, self._slab_xt = None, None, None, None
 
     def eval_slab(self, r_trg, r_src, n_src, v_src, out_slab=None):
         """This rank's slab of the potential (overwritten, like EvalDirect, fmm-wrapper.txx:501-502); with compact=True the

@@ -3,13 +3,15 @@
 // set targets, compute the potential.  The element list is a cloud of weighted point "elements" without a near zone, the
 // same one oracle/ref_shim.cpp builds on the REAL reference to produce tests/golden/ (kind "far_field").
 //
-//   bie_driver <kernel> <seed> <Nt> <Ns> <nodes_per_elem> <upsample> <dot> <self_targets> <out.bin> [<rad>]
+//   bie_driver <kernel> <seed> <Nt> <Ns> <nodes_per_elem> <upsample> <dot> <self_targets> <out.bin> [<rad> [<free_nodes>]]
 // Inputs are drawn with drand48 in the order of oracle/gen_golden.py:far_field_inputs().
 //
 // With <rad> the element list is PatchElemList instead: the same nodes, but with far-field distance <rad>, so that
 // targets have near elements, and with a synthetic deterministic "singular quadrature" — the formulas in the header of
 // oracle/ref_near_shim.cpp, which drives the REAL reference with the same list to produce tests/golden/near_field.npz.
 // ComputePotential then runs SetupSelf/SetupNear on the host and ComputeNearInterac on the device.
+// With <free_nodes> the last <free_nodes> nodes form a SECOND element list, "b_free", which is matrix-free (FreePatchElemList:
+// EvalNearInterac on the host, no K_near block); the others stay in "a_patches".  Golden: sctl_ref_boundary_near2.
 #include <sctl_amd.hpp>
 #include <sctl_amd/boundary_integral.hpp>
 
@@ -161,13 +163,42 @@ template <class Real> class PatchElemList : public ElementListBase<Real> {
     L.Block(M, &Xt[0], nt, dot, ker, elem_idx);
   }
 
- private:
+ protected:
   Vector<Real> X, Xn, w;
   Long npe, ups;
   Real rad;
 };
 
-template <class Kernel> int run(long seed, Long Nt, Long Ns, Long npe, Long ups, bool dot, bool self_trg, const char* out, double rad) {
+// matrix-free variant: u[t][k1] = 0.25 * sum_{j,k0} f[j][k0] * Block(e, x_t)[(j,k0)][k1].  EvalNearInterac receives the GLOBAL
+// element index (as in the reference, boundary_integral.txx:1122), so the list knows the index of its first element.
+template <class Real> class FreePatchElemList : public PatchElemList<Real> {
+ public:
+  FreePatchElemList() : first(0) {}
+  FreePatchElemList(const Vector<Real>& X_, const Vector<Real>& Xn_, const Vector<Real>& w_, Long nodes_per_elem, Long upsample, Real rad_, Long first_global_elem)
+      : PatchElemList<Real>(X_, Xn_, w_, nodes_per_elem, upsample, rad_), first(first_global_elem) {}
+  bool MatrixFree() const override { return true; }
+  template <class Kernel> static void EvalNearInterac(Vector<Real>& u, const Vector<Real>& f, const Vector<Real>& Xt, const Vector<Real>& normal_trg, const Kernel& ker, Real tol, const Long elem_idx, const ElementListBase<Real>* self) {
+    const FreePatchElemList& L = *dynamic_cast<const FreePatchElemList*>(self);
+    const Long e = elem_idx - L.first, nt = Xt.Dim() / 3, K1_ = (nt ? u.Dim() / nt : 0);
+    const bool dot = normal_trg.Dim() > 0;
+    for (Long t = 0; t < nt; t++) {
+      Real nrm[3] = {0, 0, 0};
+      if (dot) for (int k = 0; k < 3; k++) nrm[k] = normal_trg[t * 3 + k];
+      Matrix<Real> M;
+      L.Block(M, &Xt[t * 3], nrm, dot, ker, e);
+      for (Long k1 = 0; k1 < K1_; k1++) {
+        Real sum = 0;
+        for (Long r = 0; r < M.Dim(0); r++) sum += f[r] * M[r][k1];
+        u[t * K1_ + k1] = (Real)0.25 * sum;
+      }
+    }
+  }
+
+ private:
+  Long first;
+};
+
+template <class Kernel> int run(long seed, Long Nt, Long Ns, Long npe, Long ups, bool dot, bool self_trg, const char* out, double rad, Long nfree) {
   typedef double Real;
   srand48(seed);
   Vector<Real> xt(Nt * 3), xnt(Nt * 3), xs(Ns * 3), xn(Ns * 3), w(Ns), f(Ns * Kernel::SrcDim());
@@ -181,7 +212,13 @@ template <class Kernel> int run(long seed, Long Nt, Long Ns, Long npe, Long ups,
   Kernel ker;
   BoundaryIntegralOp<Real, Kernel> op(ker, dot, Comm::Self());
   op.SetAccuracy(1e-10);
-  if (rad > 0) op.AddElemList(PatchElemList<Real>(xs, xn, w, npe, ups, rad), "patches");
+  if (rad > 0 && nfree > 0) {   // two lists: precomputed matrices for the first Ns - nfree nodes, matrix-free for the rest
+    const Long na = Ns - nfree;
+    auto part = [](const Vector<Real>& v, Long off, Long n) { return Vector<Real>(n, (Iterator<Real>)v.begin() + off, false); };
+    PatchElemList<Real> A(part(xs, 0, na * 3), part(xn, 0, na * 3), part(w, 0, na), npe, ups, rad);
+    op.AddElemList(A, "a_patches");
+    op.AddElemList(FreePatchElemList<Real>(part(xs, na * 3, nfree * 3), part(xn, na * 3, nfree * 3), part(w, na, nfree), npe, ups, rad, A.Size()), "b_free");
+  } else if (rad > 0) op.AddElemList(PatchElemList<Real>(xs, xn, w, npe, ups, rad), "patches");
   else op.AddElemList(PointElemList<Real>(xs, xn, w, npe, ups), "points");
   if (!self_trg) {
     op.SetTargetCoord(xt);
@@ -205,7 +242,7 @@ template <class Kernel> int run(long seed, Long Nt, Long Ns, Long npe, Long ups,
   {  // SqrtScaling / InvSqrtScaling (boundary_integral.txx:616-680): element e scales by sqrt(sum of its weights)
     Vector<Real> g = f;
     op.SqrtScaling(g);
-    for (Long e = 0; e * npe < Ns; e++) {
+    for (Long e = 0; nfree == 0 && e * npe < Ns; e++) {   // (one list: element e = nodes [e npe, (e+1) npe))
       Real area = 0;
       for (Long j = e * npe; j < std::min<Long>((e + 1) * npe, Ns); j++) area += w[j];
       for (Long j = e * npe * Kernel::SrcDim(); j < std::min<Long>((e + 1) * npe, Ns) * Kernel::SrcDim(); j++)
@@ -221,7 +258,7 @@ template <class Kernel> int run(long seed, Long Nt, Long Ns, Long npe, Long ups,
 
 int main(int argc, char** argv) {
   if (argc < 10) {
-    std::cerr << "usage: bie_driver <kernel> <seed> <Nt> <Ns> <nodes_per_elem> <upsample> <dot> <self_targets> <out.bin> [<rad>]\n";
+    std::cerr << "usage: bie_driver <kernel> <seed> <Nt> <Ns> <nodes_per_elem> <upsample> <dot> <self_targets> <out.bin> [<rad> [<free_nodes>]]\n";
     return 2;
   }
   const std::string k = argv[1];
@@ -229,12 +266,13 @@ int main(int argc, char** argv) {
   const Long Nt = std::atol(argv[3]), Ns = std::atol(argv[4]), npe = std::atol(argv[5]), ups = std::atol(argv[6]);
   const bool dot = std::atoi(argv[7]) != 0, self_trg = std::atoi(argv[8]) != 0;
   const double rad = argc > 10 ? std::atof(argv[10]) : 0;
-  if (k == "Laplace3D-FxU") return run<Laplace3D_FxU>(seed, Nt, Ns, npe, ups, dot, self_trg, argv[9], rad);
-  if (k == "Laplace3D-DxU") return run<Laplace3D_DxU>(seed, Nt, Ns, npe, ups, dot, self_trg, argv[9], rad);
-  if (k == "Laplace3D-FxdU") return run<Laplace3D_FxdU>(seed, Nt, Ns, npe, ups, dot, self_trg, argv[9], rad);
-  if (k == "Stokes3D-FxU") return run<Stokes3D_FxU>(seed, Nt, Ns, npe, ups, dot, self_trg, argv[9], rad);
-  if (k == "Stokes3D-DxU") return run<Stokes3D_DxU>(seed, Nt, Ns, npe, ups, dot, self_trg, argv[9], rad);
-  if (k == "Stokes3D-FxT") return run<Stokes3D_FxT>(seed, Nt, Ns, npe, ups, dot, self_trg, argv[9], rad);
+  const Long nfree = argc > 11 ? std::atol(argv[11]) : 0;
+  if (k == "Laplace3D-FxU") return run<Laplace3D_FxU>(seed, Nt, Ns, npe, ups, dot, self_trg, argv[9], rad, nfree);
+  if (k == "Laplace3D-DxU") return run<Laplace3D_DxU>(seed, Nt, Ns, npe, ups, dot, self_trg, argv[9], rad, nfree);
+  if (k == "Laplace3D-FxdU") return run<Laplace3D_FxdU>(seed, Nt, Ns, npe, ups, dot, self_trg, argv[9], rad, nfree);
+  if (k == "Stokes3D-FxU") return run<Stokes3D_FxU>(seed, Nt, Ns, npe, ups, dot, self_trg, argv[9], rad, nfree);
+  if (k == "Stokes3D-DxU") return run<Stokes3D_DxU>(seed, Nt, Ns, npe, ups, dot, self_trg, argv[9], rad, nfree);
+  if (k == "Stokes3D-FxT") return run<Stokes3D_FxT>(seed, Nt, Ns, npe, ups, dot, self_trg, argv[9], rad, nfree);
   std::cerr << "unknown kernel " << k << '\n';
   return 2;
 }

@@ -121,3 +121,65 @@ def test_morton_order_is_a_permutation_and_local():
     assert morton_order(torch.zeros(0, dtype=torch.float64)).numel() == 0
     same = torch.ones(3 * 10, dtype=torch.float32)                               # degenerate box: stable order
     assert torch.equal(morton_order(same), torch.arange(10))
+
+
+def _realloc_worker(rank, world, port, out_dir):
+    """Two target clouds of the SAME size, the first freed before the second is allocated (the caching allocator — or malloc —
+    may hand out the same address): the cached Morton order must not survive from one to the other."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from sctl_amd.distributed import ShardedDirectSum
+    O = oracle.restatement()
+    name, Nt, Ns = "Laplace3D-FxU", 700, 200
+    rng = np.random.default_rng(21)
+    xs, f = rng.random(Ns * 3), rng.random(Ns) - 0.5
+
+    def oracle_eval(r_trg_slab, r_src, n_src, v_src, v_out):
+        v_out += torch.from_numpy(O.eval(name, r_trg_slab.numpy().copy(), r_src.numpy(), None, v_src.numpy(), nthreads=2))
+        return v_out
+
+    op = ShardedDirectSum(name, local_eval=oracle_eval)
+    ok, ptrs = True, []
+
+    def once(seed):
+        xt = torch.from_numpy(np.random.default_rng(seed).random(Nt * 3))      # a fresh tensor, version 0, dropped on return
+        ptrs.append(xt.data_ptr())
+        u = op.eval(xt, torch.from_numpy(xs), None, torch.from_numpy(f))
+        ref = O.eval(name, xt.numpy(), xs, None, f, nthreads=2)
+        return np.linalg.norm(u.numpy() - ref) <= 1e-14 * np.linalg.norm(ref)
+
+    for seed in (1, 2, 3, 4):
+        op.invalidate() if seed == 4 else None
+        ok = ok and once(seed)
+    # in-place change of a tensor the operator has seen: the version counter invalidates the cache
+    xt = torch.from_numpy(rng.random(Nt * 3))
+    op.eval(xt, torch.from_numpy(xs), None, torch.from_numpy(f))
+    xt.mul_(0.5)
+    u = op.eval(xt, torch.from_numpy(xs), None, torch.from_numpy(f))
+    ref = O.eval(name, xt.numpy(), xs, None, f, nthreads=2)
+    ok = ok and np.linalg.norm(u.numpy() - ref) <= 1e-14 * np.linalg.norm(ref)
+    with open(os.path.join(out_dir, "realloc%d" % rank), "w") as fh:
+        fh.write("ok" if ok else "bad")
+    dist.destroy_process_group()
+
+
+def test_cached_target_order_is_tied_to_the_tensor_not_its_address(tmp_path):
+    mp.spawn(_realloc_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert open(os.path.join(str(tmp_path), "realloc%d" % r)).read() == "ok"
+
+
+def test_bench_starts_its_own_ranks_when_asked_for_several_gpus():
+    """`python bench.py --gpus 2` with no rank environment must launch two ranks itself (the driver's N > 1 command line may be
+    the plain one).  Without a GPU each rank stops with bench.py's own message — which shows that two ranks were started and
+    that the parent hands a failing exit code on; with GPUs the same path is run for real by tests/test_gpu_distributed.py."""
+    import subprocess
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check of the launcher")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                       env=env, timeout=600)
+    assert r.returncode != 0
+    assert r.stderr.count("bench.py needs a GPU") >= 2, r.stderr[-2000:]

@@ -75,3 +75,75 @@ def test_sharded_and_ring_drivers_on_the_hip_path(tmp_path):
     for r in range(world):
         res = open(os.path.join(str(tmp_path), "rank%d" % r)).read()
         assert res and "BAD" not in res, (r, res)
+
+
+def _nccl_worker(rank, world, port, out_dir):
+    """One rank per GPU on backend "nccl" (= RCCL over xGMI): the path the driver's multi-GPU bench takes."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    import sctl_amd
+    from sctl_amd.distributed import ShardedDirectSum
+    g = torch.Generator(device="cuda").manual_seed(7)
+    nt, ns = (1 << 17) + 5, 30011                                  # ragged: exercises the padded all-gather too
+    xt = torch.rand(nt * 3, dtype=torch.float64, device="cuda", generator=g)
+    xs = torch.rand(ns * 3, dtype=torch.float64, device="cuda", generator=g)
+    f = torch.rand(ns, dtype=torch.float64, device="cuda", generator=g) - 0.5
+    single = sctl_amd.eval_device("Laplace3D-FxU", xt, xs, None, f)
+    ok = []
+    for compact in (True, False):
+        u = ShardedDirectSum("Laplace3D-FxU", compact=compact).eval(xt, xs, None, f)
+        ok.append(float((u - single).norm() / single.norm()) <= 2e-14)
+    nt2 = world * 4096                                             # equal slabs: the fused all_gather_into_tensor
+    u = ShardedDirectSum("Laplace3D-FxU").eval(xt[:nt2 * 3], xs, None, f)
+    ok.append(float((u - single[:nt2]).norm() / single[:nt2].norm()) <= 2e-14)
+    # the three collectives bench.py issues, called directly (with one rank they still go through RCCL)
+    mine = torch.full((1024,), float(rank + 1), dtype=torch.float64, device="cuda")
+    every = torch.empty(1024 * world, dtype=torch.float64, device="cuda")
+    dist.all_gather_into_tensor(every, mine)
+    ok.append(bool((every.view(world, 1024)[:, 0] == torch.arange(1, world + 1, dtype=torch.float64, device="cuda")).all()))
+    t = torch.tensor([float(rank)], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    ok.append(float(t.item()) == world - 1)
+    with open(os.path.join(out_dir, "nccl%d" % rank), "w") as fh:
+        fh.write(" ".join("ok" if x else "BAD" for x in ok))
+    dist.destroy_process_group()
+
+
+def test_sharded_direct_sum_over_rccl(tmp_path):
+    """Backend "nccl" with one rank per visible GPU (up to 4).  On a one-GPU box that is a single rank: the slab driver is then
+    trivial, but the process group, the all-gather, the all-reduce and the barrier still run on RCCL."""
+    import torch
+    import torch.multiprocessing as mp
+    world = max(1, min(torch.cuda.device_count(), 4))
+    mp.spawn(_nccl_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        res = open(os.path.join(str(tmp_path), "nccl%d" % r)).read()
+        assert res and "BAD" not in res, (r, res)
+
+
+def _run_bench(extra_env, *argv):
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(extra_env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_self_launches_two_ranks_end_to_end():
+    """`python bench.py --gpus 2` exactly as the driver may invoke it (no torchrun, no rank environment).  On a one-GPU box the two
+    ranks share device 0 over gloo (SCTL_AMD_BENCH_REHEARSAL=1); with two or more GPUs this is the real RCCL run."""
+    import torch
+    rehearsal = torch.cuda.device_count() < 2
+    line = _run_bench({"SCTL_AMD_BENCH_REHEARSAL": "1"} if rehearsal else {}, "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline")
+    assert line["n_gpus"] == 2 and line["steps"] == 1 and line["value"] > 1e11
+    assert line["config"]["n_trg"] == 1 << 20 and line["dtype"] == "f64" and "roofline" in line

@@ -18,9 +18,9 @@ def _cloud(seed, Nt, Ns, info, dt=np.float64):
 @pytest.mark.parametrize("name,N,dt,tol", [
     ("Laplace3D-FxU", 1 << 20, np.float64, 1e-12),      # BASELINE config 2 size, headline kernel
     ("Laplace3D-DxU", 1 << 20, np.float64, 1e-12),      # double layer on the tile-centred path at full size
-    ("Laplace3D-FDxUdU", 1 << 18, np.float64, 1e-12),   # config 2 functor (SL+DL potential+gradient)
+    ("Laplace3D-FDxUdU", 1 << 20, np.float64, 1e-12),   # config 2 (SL+DL potential+gradient) at its full size
     ("Stokes3D-FxU", 1 << 18, np.float64, 1e-12),       # config 3
-    ("Helmholtz3D-FxU", 1 << 17, np.float64, 1e-12),    # config 5 functor
+    ("Helmholtz3D-FxU", 1 << 20, np.float64, 1e-12),    # config 5 (complex wavenumber) at its full size
     ("Laplace3D-FxU", 1 << 21, np.float32, 1e-4),       # config 4 precision (tolerance vs the f64 oracle)
     ("Laplace3D-FxU", 1 << 23, np.float32, 1e-4),       # config 4 at its full size (2^23 x 2^23; ~11 s on one GPU)
 ])

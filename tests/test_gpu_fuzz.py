@@ -24,7 +24,8 @@ def test_random_cases_against_oracle(O, seed):
         info = sctl_amd.kernel_info(name)
         dt = np.float64 if rng.random() < 0.6 else np.float32
         Nt, Ns = _size(rng), _size(rng)
-        digits = int(rng.choice([-1, -1, 16, 12, 9, 5])) if dt == np.float64 else -1
+        # fp32 with more than 7 digits asked: the Newton-refined fp32 seed (MODE 1 in fp32, ukernels.hpp rsqrt_masked<float>)
+        digits = int(rng.choice([-1, -1, 16, 12, 9, 5])) if dt == np.float64 else int(rng.choice([-1, -1, 12, 9, 5]))
         scale = float(rng.choice([1.0, 1e-3, 1e3]))
         xt = (scale * rng.random(Nt * 3)).astype(dt)
         xs = (scale * rng.random(Ns * 3)).astype(dt)
@@ -46,6 +47,6 @@ def test_random_cases_against_oracle(O, seed):
             op.set_sources(xs, xn)
             u = op.eval(f, digits=digits)
             op.close()
-        tol = (1e-12 if digits < 0 or digits >= 15 else 10.0 * 10.0 ** (-digits)) if dt == np.float64 else 3e-5
+        tol = (1e-12 if digits < 0 or digits >= 15 else 10.0 * 10.0 ** (-digits)) if dt == np.float64 else (3e-5 if digits != 5 else 1e-4)
         err = rel_l2(u, ref)
         assert np.all(np.isfinite(u)) and err <= tol, (name, dt, Nt, Ns, digits, how, err)

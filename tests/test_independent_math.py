@@ -1,0 +1,93 @@
+"""The two functors the reference does not have are this repository's on every side: HIP, oracle and the functor
+text instantiated on the reference's GenericKernel.  These tests pin them to INDEPENDENT mathematics instead:
+  Helmholtz3D-FxU   against numpy complex128  sum_s exp(i k r) / (4 pi r) f_s  with a complex wavenumber;
+  Laplace3D-FDxUdU  potential against numpy  sum_s q/(4 pi r) + mu (r.n)/(4 pi r^3), gradient against central finite differences
+                    of that numpy potential (truncation error O(h^2), so the tolerance is 1e-6, not rounding).
+CPU: the oracle.  GPU: the HIP path through the C ABI."""
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+
+
+def _helmholtz_numpy(xt, xs, f, k):
+    d = xt.reshape(-1, 1, 3) - xs.reshape(1, -1, 3)
+    r = np.sqrt((d * d).sum(-1))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        G = np.where(r > 0, np.exp(1j * k * r) / (4 * np.pi * r), 0)
+    fc = f[0::2] + 1j * f[1::2]
+    u = G @ fc
+    return np.stack([u.real, u.imag], 1).ravel()
+
+
+def _laplace_pot_numpy(x, xs, xn, q, mu):
+    d = x.reshape(-1, 1, 3) - xs.reshape(1, -1, 3)
+    r2 = (d * d).sum(-1)
+    rinv = 1 / np.sqrt(r2)
+    rn = (d * xn.reshape(1, -1, 3)).sum(-1)
+    return ((q * rinv) + mu * rn * rinv ** 3).sum(1) / (4 * np.pi)
+
+
+def _helmholtz_case(seed, k):
+    rng = np.random.default_rng(seed)
+    Nt, Ns = 257, 1000
+    xt, xs, f = rng.random(Nt * 3), rng.random(Ns * 3), rng.random(Ns * 2) - 0.5
+    xt[:30] = xs[:30]                                     # ten coincident points: G = 0 there
+    return xt, xs, f, _helmholtz_numpy(xt, xs, f, k)
+
+
+def _fused_case(seed):
+    rng = np.random.default_rng(seed)
+    Nt, Ns = 100, 700
+    xt = rng.random(Nt * 3) + 1.5                         # targets away from the sources: smooth field, FD is accurate
+    xs, xn = rng.random(Ns * 3), rng.random(Ns * 3) - 0.5
+    q, mu = rng.random(Ns) - 0.5, rng.random(Ns) - 0.5
+    pot = _laplace_pot_numpy(xt, xs, xn, q, mu)
+    h = 1e-4
+    grad = np.empty((Nt, 3))
+    for j in range(3):
+        e = np.zeros(3); e[j] = h
+        xp, xm = (xt.reshape(-1, 3) + e).ravel(), (xt.reshape(-1, 3) - e).ravel()
+        grad[:, j] = (_laplace_pot_numpy(xp, xs, xn, q, mu) - _laplace_pot_numpy(xm, xs, xn, q, mu)) / (2 * h)
+    return xt, xs, xn, np.stack([q, mu], 1).ravel().copy(), pot, grad
+
+
+K_CASES = [(7.5, 0.3), (20.0, 0.0), (0.5, 2.0), (-3.0, 0.1)]
+
+
+@pytest.mark.parametrize("k", K_CASES)
+def test_oracle_helmholtz_against_numpy_complex(O, k):
+    xt, xs, f, ref = _helmholtz_case(3, complex(*k))
+    assert rel_l2(O.eval("Helmholtz3D-FxU", xt, xs, None, f, ctx=np.array(k)), ref) < 5e-15
+
+
+def test_oracle_fused_laplace_against_numpy_and_finite_differences(O):
+    xt, xs, xn, f, pot, grad = _fused_case(4)
+    u = O.eval("Laplace3D-FDxUdU", xt, xs, xn, f).reshape(-1, 4)
+    assert rel_l2(u[:, 0], pot) < 5e-15
+    assert rel_l2(u[:, 1:], grad) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", K_CASES)
+def test_hip_helmholtz_against_numpy_complex(k):
+    import sctl_amd
+    xt, xs, f, ref = _helmholtz_case(3, complex(*k))
+    assert rel_l2(sctl_amd.eval_host("Helmholtz3D-FxU", xt, xs, None, f, ctx=np.array(k)), ref) < 1e-13
+    u32 = sctl_amd.eval_host("Helmholtz3D-FxU", xt.astype(np.float32), xs.astype(np.float32), None, f.astype(np.float32), ctx=np.array(k))
+    assert rel_l2(u32, ref) < 3e-5
+
+
+@pytest.mark.gpu
+def test_hip_fused_laplace_against_numpy_and_finite_differences():
+    import sctl_amd
+    xt, xs, xn, f, pot, grad = _fused_case(4)
+    u = sctl_amd.eval_host("Laplace3D-FDxUdU", xt, xs, xn, f).reshape(-1, 4)
+    assert rel_l2(u[:, 0], pot) < 1e-13
+    assert rel_l2(u[:, 1:], grad) < 1e-6
+    # the double-layer part alone: gradient of mu (r.n)/r^3
+    f_mu = f.copy(); f_mu[0::2] = 0
+    u_mu = sctl_amd.eval_host("Laplace3D-FDxUdU", xt, xs, xn, f_mu).reshape(-1, 4)
+    f_q = f.copy(); f_q[1::2] = 0
+    u_q = sctl_amd.eval_host("Laplace3D-FDxUdU", xt, xs, xn, f_q).reshape(-1, 4)
+    assert rel_l2(u_mu + u_q, u) < 1e-14

@@ -45,21 +45,60 @@ def dims(O, c):
 IDS = ["%s-%s" % (c["kernel"], c["key"]) for c in CASES]
 
 
+def matrix_free_part(O, case, arrs, xt, xnt, xs, xn, w, f):
+    """Contribution of the matrix-free element list of a two-list case (oracle/ref_near_shim.cpp: FreePatchElemList) to the
+    potential, in numpy: per element e of that list and near target t,  u[t][k1] += 0.25 sum_{j,k0} f[j][k0] g_j M[(j,k0)][k1],
+    g_j = w_j (1 + 0.5 / (1 + |x_t - x_j|^2 / rad^2)), M = scaled kernel matrix of the element's nodes at x_t (dotted with the
+    target normal when the operator contracts).  Zero for one-list cases."""
+    inf = O.info(case["kernel"])
+    k0, k1f = inf["k0"], inf["k1"]
+    dot = bool(case["trg_normal_dot_prod"])
+    k1 = k1f // 3 if dot else k1f
+    ntrg = arrs["near_trg_cnt"].size
+    u = np.zeros(ntrg * k1)
+    nfree = case.get("free_nodes", 0)
+    if not nfree:
+        return u
+    npe, rad, ns_a = case["nodes_per_elem"], case["rad"], case["Ns"] - nfree
+    self_trg = case["Nt"] == 0
+    X = xs.reshape(-1, 3) if self_trg else xt.reshape(-1, 3)
+    N = (xn if self_trg else xnt).reshape(-1, 3)
+    trg_of_entry = np.empty(arrs["near_scatter_index"].size, dtype=np.int64)
+    for i in range(ntrg):
+        p0, c = int(arrs["near_trg_dsp"][i]), int(arrs["near_trg_cnt"][i])
+        trg_of_entry[arrs["near_scatter_index"][p0:p0 + c]] = i
+    near_dsp = np.concatenate([[0], np.cumsum(arrs["near_elem_cnt"])])
+    first = (ns_a + npe - 1) // npe                        # elements of the matrix list come first (map order: "a_patches" < "b_free")
+    for e in range(first, arrs["elem_nds_cnt"].size):
+        j0 = ns_a + (e - first) * npe
+        j1 = min(j0 + npe, case["Ns"])
+        assert j1 - j0 == arrs["elem_nds_cnt"][e] and arrs["K_near_cnt"][e] == 0
+        for entry in range(int(near_dsp[e]), int(near_dsp[e + 1])):
+            t = trg_of_entry[entry]
+            M = O.kernel_matrix(case["kernel"], X[t].copy(), xs[j0 * 3:j1 * 3].copy(), xn[j0 * 3:j1 * 3].copy()).reshape(j1 - j0, k0, k1f)
+            r2 = ((X[t] - xs[j0 * 3:j1 * 3].reshape(-1, 3)) ** 2).sum(1)
+            g = w[j0:j1] * (1 + 0.5 / (1 + r2 / rad ** 2))
+            if dot:
+                M = (M.reshape(j1 - j0, k0, k1, 3) * N[t]).sum(-1)
+            u[t * k1:(t + 1) * k1] += 0.25 * np.einsum("j,jk,jkl->l", g, f[j0 * k0:j1 * k0].reshape(-1, k0), M)
+    return u
+
+
 @pytest.mark.parametrize("case", CASES, ids=IDS)
 def test_near_restatement_matches_reference(O, oracle_mod, case):
     k0, k1 = dims(O, case)
     xt, xnt, xs, xn, w, f = near_inputs(case, k0)
     arrs = {k: gold(case, k) for k in ("elem_nds_cnt", "near_elem_cnt", "K_near_cnt", "K_near", "near_scatter_index", "near_trg_cnt", "near_trg_dsp")}
     assert arrs["near_scatter_index"].size == case["near_entries"] > 0
-    un = oracle_mod.near_apply_restatement(k0, k1, F=f, **arrs)
-    assert rel_l2(un, gold(case, "u_near")) < 1e-15
+    un = oracle_mod.near_apply_restatement(k0, k1, F=f, **arrs) + matrix_free_part(O, case, arrs, xt, xnt, xs, xn, w, f)
+    assert rel_l2(un, gold(case, "u_near")) < (1e-15 if not case.get("free_nodes") else 1e-13)
     # ComputePotential = ComputeFarField + ComputeNearInterac (boundary_integral.txx:608-614)
     self_trg = case["Nt"] == 0
     far = oracle_mod.far_field_restatement(O, case["kernel"], None if self_trg else xt, xn if self_trg else xnt, xs, xn, w, f, bool(case["trg_normal_dot_prod"]))
     assert rel_l2(far + un, gold(case, "u_total")) < 1e-10        # the reference's far field ran at tol 1e-10
     # accumulate semantics (:1131-1140)
     u0 = np.full_like(un, 0.25)
-    assert rel_l2(oracle_mod.near_apply_restatement(k0, k1, F=f, U=u0.copy(), **arrs), un + 0.25) < 1e-15
+    assert rel_l2(oracle_mod.near_apply_restatement(k0, k1, F=f, U=u0.copy(), **arrs) + matrix_free_part(O, case, arrs, xt, xnt, xs, xn, w, f), un + 0.25) < 1e-14
 
 
 def test_near_symbols_fail_loudly_without_gpu():
@@ -86,11 +125,12 @@ def test_near_create_rejects_inconsistent_arrays():
 def test_near_device_matches_reference(O, case):
     import torch
     k0, k1 = dims(O, case)
-    f = near_inputs(case, k0)[5]
+    xt, xnt, xs, xn, w, f = near_inputs(case, k0)
     arrs = {k: gold(case, k) for k in ("elem_nds_cnt", "near_elem_cnt", "K_near_cnt", "K_near", "near_scatter_index", "near_trg_cnt", "near_trg_dsp")}
     op = sctl_amd.NearOp(k0, k1, **arrs)
     assert op.near_entries == case["near_entries"] and op.operator_bytes == arrs["K_near"].size * 8 and op.density_len == f.size
-    ref = gold(case, "u_near")
+    # the device applies the precomputed matrices; a matrix-free list's share (two-list cases) is the caller's, on the host
+    ref = gold(case, "u_near") - matrix_free_part(O, case, arrs, xt, xnt, xs, xn, w, f)
     u = op.apply(f)
     assert rel_l2(u, ref) < 1e-14, rel_l2(u, ref)
     u2 = op.apply(f, U=u.copy())                                   # accumulates
@@ -141,7 +181,7 @@ def test_boundary_integral_near_field_end_to_end(tmp_path, case):
     exe = _build(tmp_path, "bie_driver")
     out = str(tmp_path / (case["key"] + ".bin"))
     args = [exe, case["kernel"], str(case["seed"]), str(case["Nt"]), str(case["Ns"]), str(case["nodes_per_elem"]), str(case["upsample"]),
-            str(case["trg_normal_dot_prod"]), str(int(case["Nt"] == 0)), out, repr(case["rad"])]
+            str(case["trg_normal_dot_prod"]), str(int(case["Nt"] == 0)), out, repr(case["rad"]), str(case.get("free_nodes", 0))]
     p = subprocess.run(args, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr
     u, un = _read_vector(out), _read_vector(out + ".near")

@@ -1,5 +1,7 @@
 """A/B timing inside ONE gpurun call (same GPU): exact kernel vs the tile-centred path, interleaved.
 usage (on the GPU box): python tools/ab_centered.py [log2 N ...]"""
+# NOTE: the SCTL_AMD_EXPERIMENT_* switches exist only in a library built with `make -C sctl_amd/csrc EXTRA=-DSCTL_AMD_EXPERIMENTS OUT=... OBJDIR=...`
+# (point SCTL_AMD_LIB at it); the shipped libsctl_amd.so ignores them.
 import os
 import subprocess
 import sys

@@ -1,5 +1,7 @@
 """Tile-centred Laplace path: time and error against the exact kernel as a function of the far/near threshold
 |x_s - c|^2 > factor * Rt^2 (SCTL_AMD_EXPERIMENT_NEAR_FACTOR; the library default is 9)."""
+# NOTE: the SCTL_AMD_EXPERIMENT_* switches exist only in a library built with `make -C sctl_amd/csrc EXTRA=-DSCTL_AMD_EXPERIMENTS OUT=... OBJDIR=...`
+# (point SCTL_AMD_LIB at it); the shipped libsctl_amd.so ignores them.
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
