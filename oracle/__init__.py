@@ -5,6 +5,8 @@ nothing under sctl_amd/ or include/ does (tests/test_boundary.py checks that).
 
   oracle.restatement()  -> Oracle     (oracle/libsctl_oracle.so, built from oracle/sctl_oracle.cpp)
   oracle.reference()    -> Reference  (oracle/_ref/libsctl_ref_<isa>.so, the real SCTL headers; None if absent)
+  oracle.dropin()       -> Reference  (the same shim built with include/sctl_amd/sctl_dropin.hpp's kernel class: the reference's call
+                                       sites running on libsctl_amd.so; the thing under test in tests/test_gpu_dropin.py)
   oracle.build()        -> compiles both (the reference only where /root/reference exists)
 """
 import ctypes as C
@@ -199,6 +201,14 @@ def reference():
     return None
 
 
+def dropin():
+    """The reference's own call sites (GenericKernel::Eval entries, ParticleFMM, BoundaryIntegralOp) compiled with the kernel class of
+    include/sctl_amd/sctl_dropin.hpp, so that their arithmetic runs in libsctl_amd.so: oracle/ref_shim.cpp with -DSCTL_REF_DROPIN.
+    Needs a GPU to evaluate anything.  None if oracle/_ref holds no such build."""
+    path = os.path.join(_HERE, "_ref", "libsctl_ref_dropin.so")
+    return Reference(path) if os.path.exists(path) else None
+
+
 def rel_l2(a, b):
     a = np.asarray(a, dtype=np.float64).ravel()
     b = np.asarray(b, dtype=np.float64).ravel()
@@ -210,11 +220,11 @@ def rel_l2(a, b):
 NEAR_INT_ARRAYS = ("elem_nds_cnt", "near_elem_cnt", "K_near_cnt", "near_scatter_index", "near_trg_cnt", "near_trg_dsp")
 
 
-def reference_near(name, xt, xn_trg, xs, xn, wts, f, trg_normal_dot_prod=False, tol=1e-10, nodes_per_elem=4, upsample=1, rad=0.1, free_nodes=0):
+def reference_near(name, xt, xn_trg, xs, xn, wts, f, trg_normal_dot_prod=False, tol=1e-10, nodes_per_elem=4, upsample=1, rad=0.1, free_nodes=0, dropin=False):
     """The REAL reference's BoundaryIntegralOp on the synthetic PatchElemList of oracle/ref_near_shim.cpp (build container only).
     Returns u_total (ComputePotential), u_near (ComputeNearInterac alone) and the near-operator arrays SetupNear built.
     free_nodes > 0: TWO element lists — the last `free_nodes` nodes form a second, matrix-free list (sctl_ref_boundary_near2)."""
-    path = os.path.join(_HERE, "_ref", "libsctl_ref_near.so")
+    path = os.path.join(_HERE, "_ref", "libsctl_ref_near_dropin.so" if dropin else "libsctl_ref_near.so")   # dropin: kernels = sctl_amd::HipKernel
     lib = C.CDLL(path)
     Ns = xs.size // 3
     Nt = 0 if xt is None else xt.size // 3

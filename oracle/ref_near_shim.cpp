@@ -16,10 +16,18 @@
 //   SelfInterac(e)     : column block i = NearInterac(e, x_i) (the r = 0 pair contributes 0) plus the diagonal term
 //                        M[(i,k0)][(i,k1)] += w_i * (0.3 + 0.1 k0 + 0.01 k1)
 // tests/cpp/bie_driver.cpp states the same formulas against include/sctl_amd/boundary_integral.hpp.
+// With -DSCTL_REF_DROPIN (oracle/Makefile: dropin) the kernel objects are sctl_amd::HipKernel<uKernel>: the reference's
+// SetupNear then gets its direct-part blocks from sctl_amd_kernel_matrix_host and its far field from sctl_amd_eval_host.
 #include <sctl.hpp>
 #include <cstring>
 #include <cstdint>
 #include <string>
+#ifdef SCTL_REF_DROPIN
+#include "../include/sctl_amd/sctl_dropin.hpp"
+template <class uKernel> using KerOf = sctl_amd::HipKernel<uKernel>;
+#else
+template <class uKernel> using KerOf = sctl::GenericKernel<uKernel>;
+#endif
 
 namespace ref_ext {
 using sctl::Long;
@@ -165,7 +173,8 @@ using namespace sctl;
 
 template <class F> static int dispatch(const char* name, F&& f) {
 #define CASE(K) if (K::Name() == name) return f(K());
-  CASE(Laplace3D_FxU) CASE(Laplace3D_DxU) CASE(Laplace3D_FxdU) CASE(Stokes3D_FxU) CASE(Stokes3D_DxU) CASE(Stokes3D_FxT)
+  CASE(KerOf<kernel_impl::Laplace3D_FxU>) CASE(KerOf<kernel_impl::Laplace3D_DxU>) CASE(KerOf<kernel_impl::Laplace3D_FxdU>)
+  CASE(KerOf<kernel_impl::Stokes3D_FxU>) CASE(KerOf<kernel_impl::Stokes3D_DxU>) CASE(KerOf<kernel_impl::Stokes3D_FxT>)
 #undef CASE
   return -1;
 }

@@ -10,10 +10,21 @@
 // repository's own functor text, written against the reference's documented functor contract
 // (doc/tutorial/kernels.rst:11-84) and instantiated on the reference's GenericKernel so the
 // reference's evaluator machinery is the oracle for them too.
+//
+// Compiled a second time with -DSCTL_REF_DROPIN (oracle/Makefile: dropin -> oracle/_ref/libsctl_ref_dropin.so, linked with
+// libsctl_amd.so): every kernel object is then include/sctl_amd/sctl_dropin.hpp's HipKernel<uKernel>, i.e. the reference's
+// UNMODIFIED GenericKernel::Eval call sites, ParticleFMM and BoundaryIntegralOp run with their arithmetic on the GPU —
+// INTEGRATION.md's binding executed (tests/test_gpu_dropin.py compares it with the golden outputs of the plain build).
 #include <sctl.hpp>
 #include <cstring>
 #include <cstdint>
 #include <string>
+#ifdef SCTL_REF_DROPIN
+#include "../include/sctl_amd/sctl_dropin.hpp"
+template <class uKernel> using KerOf = sctl_amd::HipKernel<uKernel>;
+#else
+template <class uKernel> using KerOf = sctl::GenericKernel<uKernel>;
+#endif
 
 namespace ref_ext {
 using sctl::Integer;
@@ -133,9 +144,10 @@ template <class Ker, class Real> int matrix_one(Long Nt, Long Ns, const void* xt
 
 template <class F> int dispatch(const char* name, F&& f) {
 #define CASE(K) if (K::Name() == name) return f(K());
-  CASE(Laplace3D_FxU) CASE(Laplace3D_DxU) CASE(Laplace3D_FxdU) CASE(Stokes3D_FxU) CASE(Stokes3D_DxU)
-  CASE(Stokes3D_FxT) CASE(Stokes3D_FSxU) CASE(Stokes3D_FxUP)
-  CASE(GenericKernel<ref_ext::Laplace3D_FDxUdU>) CASE(GenericKernel<ref_ext::Helmholtz3D_FxU>)
+  CASE(KerOf<kernel_impl::Laplace3D_FxU>) CASE(KerOf<kernel_impl::Laplace3D_DxU>) CASE(KerOf<kernel_impl::Laplace3D_FxdU>)
+  CASE(KerOf<kernel_impl::Stokes3D_FxU>) CASE(KerOf<kernel_impl::Stokes3D_DxU>) CASE(KerOf<kernel_impl::Stokes3D_FxT>)
+  CASE(KerOf<kernel_impl::Stokes3D_FSxU>) CASE(KerOf<kernel_impl::Stokes3D_FxUP>)
+  CASE(KerOf<ref_ext::Laplace3D_FDxUdU>) CASE(KerOf<ref_ext::Helmholtz3D_FxU>)
 #undef CASE
   return -1;
 }

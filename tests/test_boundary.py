@@ -117,3 +117,19 @@ def test_rand48_matches_posix():
     g = Rand48(3)
     b = np.concatenate([g.drand48(100) for _ in range(200)])
     assert np.array_equal(a, b)
+
+
+def test_reference_side_binding_compiles_against_the_real_reference(oracle_mod):
+    """include/sctl_amd/sctl_dropin.hpp (HipKernel<uKernel> : sctl::GenericKernel<uKernel>) was compiled with the reference's own
+    ParticleFMM / BoundaryIntegralOp by the build (oracle/Makefile `ref`); the resulting shim loads next to libsctl_amd.so and reports
+    the reference's kernel table.  (What it computes is checked on the GPU: tests/test_gpu_dropin.py.)"""
+    if not os.path.isdir("/root/reference/include/sctl") and oracle_mod.dropin() is None:
+        pytest.skip("no reference tree where the build ran: nothing to compile against")
+    sctl_amd.lib()
+    D = oracle_mod.dropin()
+    assert D is not None, "oracle/_ref/libsctl_ref_dropin.so missing: run `make -C oracle ref` after building libsctl_amd.so"
+    for name in sctl_amd.KERNEL_NAMES:
+        a, b = D.info(name), sctl_amd.kernel_info(name)
+        assert (a["k0"], a["k1"], a["nd"], a["flops"]) == (b["k0"], b["k1"], b["nd"], b["flops"]) and abs(a["scale"] - b["scale"]) < 1e-15
+    out = subprocess.run(["ldd", os.path.join(ROOT, "oracle", "_ref", "libsctl_ref_dropin.so")], capture_output=True, text=True).stdout
+    assert "libsctl_amd.so" in out
