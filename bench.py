@@ -35,11 +35,17 @@ WORKLOADS = {
 PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}   # vector FMA peaks, BASELINE.md §3 / MI355X_MICROARCH.md chip table
 
 
+def cpu_impl():
+    """The CPU side of the `cpu_baseline` legs — the ONLY place bench.py touches oracle/ (a reported comparator, never the thing measured):
+    the reference's own OpenMP + Vec<> path compiled from its headers (oracle/_ref, kind "reference"), else the CPU restatement ("port")."""
+    import oracle
+    return oracle.reference() or oracle.restatement()
+
+
 def cpu_baseline(kernel, N, dtype, budget_s=12.0):
     """The reference's own OpenMP + Vec<> path (oracle/_ref, kind "reference") — or the CPU restatement ("port") when the
     compiled reference is not usable on this host — timed on a bounded target subset against ALL sources."""
-    import oracle
-    impl = oracle.reference() or oracle.restatement()
+    impl = cpu_impl()
     info = impl.info(kernel)
     dt = np.float64 if dtype == "f64" else np.float32
     rng = np.random.default_rng(0)
@@ -134,6 +140,86 @@ def bench_near(args):
     print(json.dumps(line), flush=True)
 
 
+def bench_lists(args):
+    """Extra workload (second half): the near-field (U-list) pass of a uniform tree level as ONE launch of the
+    batched list kernel (sctl_amd_lists_*; the per-box-pair call shape of fmm-wrapper.txx:756-786).  2^21 uniform points in 16^3 leaf
+    boxes (~512 per box), every box against itself and its up to 26 neighbours, targets == sources (the self-interaction a tree
+    code has): 9.5e4 lists, 2.6e10 pair interactions per step.  Compute-bound like the all-pairs sum: same flop convention, same peak."""
+    import torch
+    import sctl_amd
+    from sctl_amd.lists import grid_neighbour_lists
+    if args.gpus != 1:
+        raise SystemExit("bench.py --workload p2p_lists runs on one GPU (a rank evaluates the lists of the boxes it owns)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: sctl_amd has no CPU path to measure")
+    kernel, grid, N = "Laplace3D-FxU", 16, 1 << 21
+    rng = np.random.default_rng(0)
+    x = rng.random((N, 3))
+    box = (np.floor(x[:, 0] * grid) * grid + np.floor(x[:, 1] * grid)) * grid + np.floor(x[:, 2] * grid)
+    order = np.argsort(box, kind="stable")
+    x = x[order].ravel().copy()                                   # particles stored box by box, as a tree keeps them
+    counts = np.bincount(box.astype(np.int64), minlength=grid ** 3)
+    lists = grid_neighbour_lists(grid, counts, counts)
+    f = rng.random(N) - 0.5
+    plan = sctl_amd.ListsPlan(kernel, np.float64, *lists, N, N)
+    dx, df = torch.from_numpy(x).cuda(), torch.from_numpy(f).cuda()
+    u = torch.zeros(N, dtype=torch.float64, device="cuda")
+
+    def step():
+        u.zero_()
+        plan.eval_device(dx, dx, None, df, v_trg=u, digits=args.digits)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    tic = time.perf_counter()
+    for e0, e1 in ev:
+        u.zero_()
+        e0.record()
+        plan.eval_device(dx, dx, None, df, v_trg=u, digits=args.digits)
+        e1.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - tic
+    k_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    fpp = sctl_amd.flops_per_pair(kernel)
+    achieved = plan.pairs * fpp / (k_ms * 1e-3) / 1e12
+    line = {"metric": "pair-interactions/s, near-field lists (P2P) of a uniform tree level", "value": plan.pairs / (elapsed / args.steps), "unit": "pair-interactions/s",
+            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "batched list evaluation: %d (target box x source box) lists, 2^21 uniform points in 16^3 boxes (%d..%d per box), targets == sources, %s"
+                                   % (lists[0].size, counts.min(), counts.max(), kernel), "kernel": kernel, "lists": int(lists[0].size), "pairs_per_step": plan.pairs,
+                       "work_items": plan.work_items, "trg_per_lane": plan.trg_per_lane, "digits": args.digits},
+            "roofline": {"bound": "mfma", "pipe": "fp64 VALU", "achieved": achieved, "peak": PEAK_TFLOPS["f64"], "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS["f64"],
+                         "traffic": read_traffic("p2p_lists"), "flops_per_pair": fpp, "kernel_ms": k_ms,
+                         "note": "vector-FMA bound: algorithmic flops = listed pairs x (3 + FLOPS() + 2 K0 K1); one launch per step"}}
+    if not args.no_cpu_baseline:
+        from concurrent.futures import ThreadPoolExecutor
+        R = cpu_impl()
+        nthreads = min(os.cpu_count() or 1, 32)
+        nb_sample = 512                                            # target boxes of the sample (all their lists)
+        to, tc, so, sc = lists
+        sel = np.flatnonzero(np.isin(to, np.unique(to)[:nb_sample]))
+        uh = np.zeros(N)
+
+        def work(chunk):                                           # a worker owns whole target boxes: no two threads write one range
+            for l in chunk:
+                t0, t1, s0, s1 = int(to[l]), int(to[l] + tc[l]), int(so[l]), int(so[l] + sc[l])
+                kw = dict(omp=False) if R.kind == "reference" else dict(nthreads=1)
+                R.eval(kernel, x[t0 * 3:t1 * 3], x[s0 * 3:s1 * 3], None, f[s0:s1], v_trg=uh[t0:t1], **kw)
+        boxes = np.array_split(np.unique(to[sel]), nthreads * 4)
+        chunks = [sel[np.isin(to[sel], b)] for b in boxes]
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(nthreads) as ex:
+            list(ex.map(work, chunks))
+        secs = time.perf_counter() - t0
+        pairs = int((tc[sel] * sc[sel]).sum())
+        line["cpu_baseline"] = {"value": pairs / secs, "unit": "pair-interactions/s", "cores": nthreads, "kind": R.kind,
+                                "sample": "the %d lists of the first %d target boxes, one GenericKernel::Eval per list from %d worker threads (as PVFMM calls it), %.1f s"
+                                          % (sel.size, nb_sample, nthreads, secs)}
+    print(json.dumps(line), flush=True)
+
+
 def self_launch(n_gpus, argv):
     """`python bench.py --gpus N` with N > 1 and no rank environment: start the N ranks ourselves, one process per GPU, the way the
     driver's own multi-GPU command does (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...).
@@ -157,7 +243,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="laplace_sl", choices=sorted(WORKLOADS) + ["near_apply"])
+    ap.add_argument("--workload", default="laplace_sl", choices=sorted(WORKLOADS) + ["near_apply", "p2p_lists"])
     ap.add_argument("--digits", type=int, default=-1, help="accuracy request; -1 = full precision (the reference default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -165,6 +251,8 @@ def main():
         raise SystemExit("bench.py: --gpus must be >= 1")
     if args.workload == "near_apply":
         return bench_near(args)
+    if args.workload == "p2p_lists":
+        return bench_lists(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
 

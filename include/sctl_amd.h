@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SCTL_AMD_VERSION 100 /* 0.1.0 */
+#define SCTL_AMD_VERSION 200 /* 0.2.0 */
 
 /* Precision of every array in a call (the reference's template parameter Real). */
 enum sctl_amd_real { SCTL_AMD_F64 = 0, SCTL_AMD_F32 = 1 };
@@ -48,7 +48,7 @@ enum sctl_amd_kernel {
   SCTL_AMD_STOKES3D_FXUP = 7,    /* "Stokes3D-FxUP"    3x4, velocity + pressure                 kernel_functions.hpp:174-198 */
   SCTL_AMD_LAPLACE3D_FDXUDU = 8, /* "Laplace3D-FDxUdU" 2x4, normal, {q, mu} -> {u, grad u}      (new, BASELINE config 2)     */
   SCTL_AMD_HELMHOLTZ3D_FXU = 9,  /* "Helmholtz3D-FxU"  2x2, exp(ikr)/(4 pi r), ctx = {Re k, Im k} as 2 doubles (new, config 5) */
-  SCTL_AMD_NUM_KERNELS = 10
+  SCTL_AMD_NUM_KERNELS = 10      /* built-in kernels; ids from here on belong to kernels registered by plugins (below) */
 };
 
 enum sctl_amd_status {
@@ -75,6 +75,32 @@ const char* sctl_amd_kernel_name(int kernel);   /* NULL for an unknown id */
 int sctl_amd_kernel_info(int kernel, int* src_dim, int* trg_dim, int* normal_dim, int* flops, double* scale, int* ctx_bytes);
 /* Algorithmic flops per pair interaction by SURVEY.md §8(d): 3 + FLOPS() + 2*SrcDim*TrgDim. */
 int sctl_amd_flops_per_pair(int kernel);
+int sctl_amd_num_kernels(void);                 /* built-in + registered: valid ids are 0 .. sctl_amd_num_kernels()-1 */
+
+/* ---- user-defined kernel functors (the device side of doc/tutorial/kernels.rst:11-84) ------------------------ */
+/* SCTL lets a user write a functor (Name, FLOPS, uKerScaleFactor, uKerMatrix) and get Eval / KernelMatrix for it from
+ * GenericKernel<uKernel> (generic-kernel.hpp:31-152).  The device counterpart: the user writes the functor's device form (a struct
+ * with pack()/pair(), see include/sctl_amd/device/kernel_plugin.hpp and the built-in ones in device/ukernels.hpp), compiles it
+ * with hipcc for gfx950 into a shared object, and registers it; every entry of this ABI then accepts its id, and the header
+ * wrappers find it by Name().  desc->launch_table points at the sctl_amd::KernelEntry that device/launch.hpp's
+ * make_entry<Ker>() builds (function pointers into the plugin's own code object); abi_version and desc_bytes guard against a
+ * plugin compiled with other device headers.  Returns the new kernel id (>= SCTL_AMD_NUM_KERNELS) or a negative error code
+ * (a name that is already registered is refused).  Registered kernels live until the process ends. */
+#define SCTL_AMD_DEVICE_ABI 2
+typedef struct sctl_amd_kernel_desc {
+  int abi_version;          /* SCTL_AMD_DEVICE_ABI of the headers the plugin was compiled with */
+  int desc_bytes;           /* sizeof(sctl_amd_kernel_desc) */
+  int entry_bytes;          /* sizeof(sctl_amd::KernelEntry) */
+  int src_dim, trg_dim, normal_dim, flops, ctx_bytes;
+  double scale;             /* uKerScaleFactor<double>() */
+  const char* name;         /* Name() */
+  const void* launch_table; /* const sctl_amd::KernelEntry* */
+} sctl_amd_kernel_desc;
+int sctl_amd_register_kernel(const sctl_amd_kernel_desc* desc);
+/* dlopen()s a plugin; its static initialisers (SCTL_AMD_REGISTER_KERNEL in device/kernel_plugin.hpp) register its kernels.
+ * Returns the number of kernels the plugin added (>= 0) or a negative error code.  A C++ program may instead simply link the
+ * plugin's object file. */
+int sctl_amd_load_plugin(const char* path);
 
 /* ---- the hot path: GenericKernel::Eval ------------------------------------------------------------------- */
 /* Device-resident form.  All five arrays are DEVICE pointers on the current HIP device; `stream` is a
@@ -171,9 +197,56 @@ int sctl_amd_near_apply_host(sctl_amd_near* op, const void* F, void* U);        
 int sctl_amd_near_apply_device(sctl_amd_near* op, const void* F, void* U, void* stream);   /* DEVICE arrays, enqueue */
 /* Sizes of an operator: density and potential lengths, near-list entries, bytes of K_near resident in HBM (the
  * algorithmic traffic of one application), workgroups of the GEMV launch.  Any output pointer may be NULL. */
+/* The whole of BoundaryIntegralOp::ComputePotential (boundary_integral.txx:608-614: far field, then the near-zone correction added
+ * to it) on the devices of a direct-sum operator handle.  set_near attaches the near-field operator of the same BoundaryIntegralOp —
+ * the arrays of sctl_amd_near_create, for the operator's CURRENT targets (Ntrg = the Nt of sctl_amd_op_set_targets; call again
+ * after new targets) — block-partitioned like the targets: device g keeps, of every element block, the columns whose targets lie
+ * in its slab.  eval_potential then uploads both densities once (v_src_far at the far-field nodes, f_near at the element nodes:
+ * sum(elem_nds_cnt)*SrcDim values), runs far field (+ weights, + target-normal contraction) and near field back to back on each
+ * device's stream, the near field ACCUMULATING into the far-field result where it lies, and downloads the potential once.
+ * trg_dim: TrgDim, or TrgDim/3 when target normals are set.  Results equal sctl_amd_op_eval followed by sctl_amd_near_apply_host up
+ * to the order in which the far field and a target's near entries are added (and do not depend on the number of devices).
+ * Nelem = 0 with null arrays detaches. */
+int sctl_amd_op_set_near(sctl_amd_op* op, int src_dim, int trg_dim, int64_t Nelem, const int64_t* elem_nds_cnt, const int64_t* near_elem_cnt,
+                         const int64_t* K_near_cnt, const void* K_near, const int64_t* near_scatter_index, const int64_t* near_trg_cnt,
+                         const int64_t* near_trg_dsp);
+int sctl_amd_op_eval_potential(sctl_amd_op* op, const void* v_src_far, const void* f_near, void* v_trg, int accumulate, int digits, const void* ctx,
+                               int ctx_bytes);
+
 int sctl_amd_near_info(const sctl_amd_near* op, int64_t* density_len, int64_t* potential_len, int64_t* near_entries,
                        int64_t* operator_bytes, int64_t* workgroups);
 void sctl_amd_near_destroy(sctl_amd_near* op);
+
+/* ---- batched list evaluation: many (target range x source range) direct sums in ONE launch ------------------------ */
+/* The near-field (P2P, U-list) shape of a tree code — SURVEY.md §8f row 4, second half: PVFMM calls the kernel once per
+ * (target box, source box) pair through pvfmm::GenericKernel<PVFMMKernelFn_<Ker>> on sub-ranges of the particle arrays
+ * (fmm-wrapper.txx:756-786); boxes hold 1-500 points, so on a GPU the pairs must share a launch.  List l adds to the targets
+ * [trg_off[l], trg_off[l] + trg_cnt[l]) the potential of the sources [src_off[l], src_off[l] + src_cnt[l]):
+ *     v_trg[t] += scale * sum_{s in list l} U(x_t - x_s, n_s) v_src[s]         (ACCUMULATED into, like GenericKernel::Eval)
+ * Offsets and counts are in POINTS.  The target ranges of any two lists must be IDENTICAL or DISJOINT (the leaf boxes of a
+ * tree): every target is then owned by one wave, sums run in list order in registers and are written once — deterministic, no
+ * atomics; anything else is SCTL_AMD_ERR_BAD_ARGUMENT.  Source ranges may overlap freely.  The four index arrays are HOST
+ * arrays (nlists entries each), read by create() only.
+ * A plan keeps the grouped, cost-ordered work list on `device`; evaluating it is one kernel launch.  eval_device: DEVICE
+ * arrays on the plan's device, which must be the current device; enqueues on `stream` and returns.  eval_host: HOST arrays.
+ * A handle may be used from one thread at a time. */
+typedef struct sctl_amd_lists sctl_amd_lists;
+int sctl_amd_lists_create(int kernel, int real, int device, int64_t nlists, const int64_t* trg_off, const int64_t* trg_cnt, const int64_t* src_off,
+                          const int64_t* src_cnt, int64_t Nt, int64_t Ns, sctl_amd_lists** plan);
+int sctl_amd_lists_eval_device(sctl_amd_lists* plan, const void* r_trg, const void* r_src, const void* n_src, const void* v_src, void* v_trg,
+                               int digits, const void* ctx, int ctx_bytes, void* stream);
+int sctl_amd_lists_eval_host(sctl_amd_lists* plan, const void* r_trg, const void* r_src, const void* n_src, const void* v_src, void* v_trg,
+                             int digits, const void* ctx, int ctx_bytes);
+/* pair interactions of one evaluation, work items (waves) and source ranges of the launch, targets per lane.  NULL = skip. */
+int sctl_amd_lists_info(const sctl_amd_lists* plan, int64_t* pairs, int64_t* work_items, int64_t* source_ranges, int* trg_per_lane);
+void sctl_amd_lists_destroy(sctl_amd_lists* plan);
+/* One-shot forms (plan, evaluate, release).  _device: arrays on the current device; returns after the stream has finished. */
+int sctl_amd_eval_lists_device(int kernel, int real, int64_t nlists, const int64_t* trg_off, const int64_t* trg_cnt, const int64_t* src_off,
+                               const int64_t* src_cnt, int64_t Nt, int64_t Ns, const void* r_trg, const void* r_src, const void* n_src,
+                               const void* v_src, void* v_trg, int digits, const void* ctx, int ctx_bytes, void* stream);
+int sctl_amd_eval_lists_host(int kernel, int real, int64_t nlists, const int64_t* trg_off, const int64_t* trg_cnt, const int64_t* src_off,
+                             const int64_t* src_cnt, int64_t Nt, int64_t Ns, const void* r_trg, const void* r_src, const void* n_src,
+                             const void* v_src, void* v_trg, int digits, const void* ctx, int ctx_bytes, int device);
 
 /* ---- accounting (the reference's Profile::IncrementCounter(FLOP, Ns*Nt*FLOPS()), generic-kernel.txx:188) ---- */
 /* Process-wide counters, updated atomically by every eval / kernel_matrix call. */

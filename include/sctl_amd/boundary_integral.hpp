@@ -167,22 +167,7 @@ template <class Real, class Kernel> class BoundaryIntegralOp {
     const Long Nsrc = X_far.Dim() / COORD_DIM;
     const Long Ntrg = Xtrg.Dim() / COORD_DIM;
     SCTL_AMD_ASSERT(F.Dim() == Dim(0));
-    // Density at the far-field quadrature nodes, one element list at a time (each list owns a contiguous run of surface nodes and
-    // of far-field nodes); the quadrature weights are NOT applied here: they live on the device (boundary_integral.txx:1040-1052).
-    if (F_far.Dim() != Nsrc * KDIM0) F_far.ReInit(Nsrc * KDIM0);
-    for (size_t lst = 0; lst < elem_lst_name.size(); lst++) {
-      const NodeRange surf = ListNodes(lst, elem_nds_cnt, elem_nds_dsp), far = ListNodes(lst, elem_nds_cnt_far, elem_nds_dsp_far);
-      const Vector<Real> f_in((surf.end - surf.begin) * KDIM0, (Iterator<Real>)F.begin() + surf.begin * KDIM0, false);
-      Real* const dst = F_far.begin() + far.begin * KDIM0;
-      Vector<Real> f_out((far.end - far.begin) * KDIM0, dst, false);
-      elem_lst_map.at(elem_lst_name[lst])->GetFarFieldDensity(f_out, f_in);
-      if (f_out.Dim() == 0) {   // the list's answer for "far-field nodes are the surface nodes": the density passes through
-        SCTL_AMD_ASSERT(far.end - far.begin == surf.end - surf.begin);
-        std::copy(f_in.begin(), f_in.begin() + f_in.Dim(), dst);
-      } else {
-        SCTL_AMD_ASSERT(f_out.begin() == dst);   // written into the view, not into a reallocated vector
-      }
-    }
+    GatherFarFieldDensity(F);
     const Integer KDIM1_ = (trg_normal_dot_prod_ ? KDIM1 / COORD_DIM : KDIM1);
     if (U.Dim() != Ntrg * KDIM1_) U.ReInit(Ntrg * KDIM1_);
     U.SetZero();
@@ -198,11 +183,31 @@ template <class Real, class Kernel> class BoundaryIntegralOp {
   void SqrtScaling(Vector<Real>& U) const { ScaleByElementArea(U, false); }
   void InvSqrtScaling(Vector<Real>& U) const { ScaleByElementArea(U, true); }
 
-  // boundary_integral.txx:608-614
+  // boundary_integral.txx:608-614: far field, then the near-zone correction added to it.  Here both run in ONE pass over the devices of
+  // the far-field operator (sctl_amd_op_eval_potential): the densities go down once, the near field is accumulated into the far-field
+  // result where it lies (each device holds the columns of K_near that belong to its target slab), the potential comes up once.
   void ComputePotential(Vector<Real>& U, const Vector<Real>& F) const {
     Setup();
-    ComputeFarField(U, F);
-    ComputeNearInterac(U, F);
+    const Long Nelem = near_elem_cnt.Dim();
+    const Long N_near = (Nelem ? near_elem_dsp[Nelem - 1] + near_elem_cnt[Nelem - 1] : 0);
+    if (!N_near || !far_op) {   // no near zone (or nothing to evaluate on the devices): the two legs as they are
+      ComputeFarField(U, F);
+      ComputeNearInterac(U, F);
+      return;
+    }
+    const Integer KDIM1_ = (trg_normal_dot_prod_ ? KDIM1 / COORD_DIM : KDIM1);
+    const Long Ntrg = Xtrg.Dim() / COORD_DIM;
+    GatherFarFieldDensity(F);
+    if (U.Dim() != Ntrg * KDIM1_) U.ReInit(Ntrg * KDIM1_);
+    if (!near_attached) {
+      CheckStatus(sctl_amd_op_set_near(far_op, (int)KDIM0, (int)KDIM1_, Nelem, PtrOf(elem_nds_cnt), PtrOf(near_elem_cnt), PtrOf(K_near_cnt),
+                                       K_near.Dim() ? (const void*)K_near.begin() : nullptr, PtrOf(near_scatter_index), PtrOf(near_trg_cnt), PtrOf(near_trg_dsp)),
+                  "sctl_amd_op_set_near");
+      near_attached = true;
+    }
+    CheckStatus(sctl_amd_op_eval_potential(far_op, F_far.begin(), F.begin(), U.begin(), /*accumulate*/ 0, fmm_digits(), ker_.GetCtxPtr(), (int)Kernel::CTX_BYTES),
+                "sctl_amd_op_eval_potential");
+    AddMatrixFreeNearField(U, F);
   }
 
   // boundary_integral.txx:1079-1142 (private in the reference).  U is ACCUMULATED into when it has the right size.
@@ -226,10 +231,40 @@ template <class Real, class Kernel> class BoundaryIntegralOp {
       CheckStatus(rc, "sctl_amd_near_create");
     }
     CheckStatus(sctl_amd_near_apply_host(near_op, F.begin(), U.begin()), "sctl_amd_near_apply_host");
-    // matrix-free element lists: evaluated by the user's code on the host (:1104-1125), then scattered like the rest
+    AddMatrixFreeNearField(U, F);
+  }
+
+ private:
+  // Density at the far-field quadrature nodes, one element list at a time (each list owns a contiguous run of surface nodes and
+  // of far-field nodes); the quadrature weights are NOT applied here: they live on the device (boundary_integral.txx:1040-1052).
+  void GatherFarFieldDensity(const Vector<Real>& F) const {
+    const Long Nsrc = X_far.Dim() / COORD_DIM;
+    SCTL_AMD_ASSERT(F.Dim() == Dim(0));
+    if (F_far.Dim() != Nsrc * KDIM0) F_far.ReInit(Nsrc * KDIM0);
+    for (size_t lst = 0; lst < elem_lst_name.size(); lst++) {
+      const NodeRange surf = ListNodes(lst, elem_nds_cnt, elem_nds_dsp), far = ListNodes(lst, elem_nds_cnt_far, elem_nds_dsp_far);
+      const Vector<Real> f_in((surf.end - surf.begin) * KDIM0, (Iterator<Real>)F.begin() + surf.begin * KDIM0, false);
+      Real* const dst = F_far.begin() + far.begin * KDIM0;
+      Vector<Real> f_out((far.end - far.begin) * KDIM0, dst, false);
+      elem_lst_map.at(elem_lst_name[lst])->GetFarFieldDensity(f_out, f_in);
+      if (f_out.Dim() == 0) {   // the list's answer for "far-field nodes are the surface nodes": the density passes through
+        SCTL_AMD_ASSERT(far.end - far.begin == surf.end - surf.begin);
+        std::copy(f_in.begin(), f_in.begin() + f_in.Dim(), dst);
+      } else {
+        SCTL_AMD_ASSERT(f_out.begin() == dst);   // written into the view, not into a reallocated vector
+      }
+    }
+  }
+
+  // Matrix-free element lists: their near zone is evaluated by the user's code on the host (boundary_integral.txx:1104-1125) and
+  // scattered to the targets like the device part (:1129-1140).
+  void AddMatrixFreeNearField(Vector<Real>& U, const Vector<Real>& F) const {
     bool any_matrix_free = false;
     for (const auto& name : elem_lst_name) any_matrix_free = any_matrix_free || elem_lst_map.at(name)->MatrixFree();
     if (!any_matrix_free) return;
+    const Integer KDIM1_ = (trg_normal_dot_prod_ ? KDIM1 / COORD_DIM : KDIM1);
+    const Long Ntrg = Xtrg.Dim() / COORD_DIM, Nelem = near_elem_cnt.Dim();
+    const Long N_near = (Nelem ? near_elem_dsp[Nelem - 1] + near_elem_cnt[Nelem - 1] : 0);
     Vector<Real> U_near(N_near * KDIM1_);
     U_near.SetZero();
     for (Long i = 0; i < (Long)elem_lst_name.size(); i++) {
@@ -252,7 +287,6 @@ template <class Real, class Kernel> class BoundaryIntegralOp {
         for (Long k = 0; k < KDIM1_; k++) U[i * KDIM1_ + k] += U_near[near_scatter_index[p] * KDIM1_ + k];
   }
 
- private:
   static void concat(Vector<Real>& out, const std::vector<Vector<Real>>& parts) {
     Long n = 0;
     for (const auto& p : parts) n += p.Dim();
@@ -568,10 +602,13 @@ template <class Real, class Kernel> class BoundaryIntegralOp {
   void ReleaseFarOp() const {
     if (far_op) sctl_amd_op_destroy(far_op);
     far_op = nullptr;
+    near_attached = false;
   }
   void ReleaseNearOp() const {
     if (near_op) sctl_amd_near_destroy(near_op);
     near_op = nullptr;
+    if (near_attached && far_op) CheckStatus(sctl_amd_op_set_near(far_op, (int)KDIM0, 1, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr), "sctl_amd_op_set_near");
+    near_attached = false;
   }
   static const int64_t* PtrOf(const Vector<Long>& v) {
     static_assert(sizeof(Long) == sizeof(int64_t), "Long must be 64 bits wide");
@@ -604,7 +641,8 @@ template <class Real, class Kernel> class BoundaryIntegralOp {
   mutable std::vector<Matrix<Real>> K_self;
   mutable Vector<Real> Xtrg_near, Xn_trg_near, K_near;
   mutable Vector<Long> near_elem_cnt, near_elem_dsp, near_scatter_index, near_trg_cnt, near_trg_dsp, K_near_cnt, K_near_dsp;
-  mutable sctl_amd_near* near_op = nullptr;
+  mutable sctl_amd_near* near_op = nullptr;                 // ComputeNearInterac on its own (device 0)
+  mutable bool near_attached = false;                       // K_near partitioned over far_op's devices (ComputePotential)
 };
 
 }  // namespace sctl_amd

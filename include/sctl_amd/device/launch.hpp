@@ -2,6 +2,7 @@
 // ~200 kernel instantiations compile in parallel.  capi.hip only sees function pointers.
 #pragma once
 #include "eval_kernel.hpp"
+#include "lists_kernel.hpp"
 
 namespace sctl_amd {
 
@@ -11,6 +12,7 @@ constexpr int kNumMode = 3;                    // rsqrt refinement: seed, Newton
 
 template <class R> using EvalLaunch = void (*)(const EvalArgs<R>&, dim3 grid, hipStream_t);
 template <class R> using MatrixBatchLaunch = void (*)(const MatTile* tiles, int64_t ntiles, const R* xt, const R* xs, const R* xn, R* M, R scale, const KerCtx&, hipStream_t);
+template <class R> using ListsLaunch = void (*)(const ListArgs<R>&, int64_t nitems, hipStream_t);
 template <class R> using MatrixLaunch = void (*)(int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* xn, R* M, R scale, const KerCtx&, dim3 grid, hipStream_t);
 
 struct KernelEntry {
@@ -24,6 +26,8 @@ struct KernelEntry {
   MatrixLaunch<float> matrix_f32[kNumMode];
   MatrixBatchLaunch<double> matrix_batch_f64[kNumMode];
   MatrixBatchLaunch<float> matrix_batch_f32[kNumMode];
+  ListsLaunch<double> lists_f64[kNumMode][2];       // [mode][targets per lane: 1, 2]  (lists_kernel.hpp)
+  ListsLaunch<float> lists_f32[kNumMode][2];
 };
 
 template <class Ker, class R, int MODE, int T> void launch_eval(const EvalArgs<R>& a, dim3 grid, hipStream_t st) {
@@ -37,6 +41,10 @@ template <class Ker, class R, int MODE> void launch_matrix(int64_t Nt, int64_t N
 template <class Ker, class R, int MODE> void launch_matrix_batch(const MatTile* tiles, int64_t ntiles, const R* xt, const R* xs, const R* xn, R* M, R scale,
                                                                  const KerCtx& ctx, hipStream_t st) {
   hipLaunchKernelGGL((matrix_batch_kernel<Ker, R, MODE>), dim3((unsigned)ntiles), dim3(kBlock), 0, st, tiles, xt, xs, xn, M, scale, ctx);
+}
+
+template <class Ker, class R, int MODE, int T> void launch_lists(const ListArgs<R>& a, int64_t nitems, hipStream_t st) {
+  hipLaunchKernelGGL((lists_kernel<Ker, R, MODE, T>), dim3((unsigned)nitems), dim3(kListWave), 0, st, a);
 }
 
 template <class Ker> KernelEntry make_entry(int ctx_bytes) {
@@ -55,6 +63,10 @@ template <class Ker> KernelEntry make_entry(int ctx_bytes) {
   e.matrix_batch_f64[2] = launch_matrix_batch<Ker, double, 2>;
   e.matrix_batch_f32[0] = launch_matrix_batch<Ker, float, 0>; e.matrix_batch_f32[1] = launch_matrix_batch<Ker, float, 1>;
   e.matrix_batch_f32[2] = launch_matrix_batch<Ker, float, 1>;
+#define SCTL_AMD_LROW(R, arr, M, MM) arr[M][0] = launch_lists<Ker, R, MM, 1>; arr[M][1] = launch_lists<Ker, R, MM, 2>;
+  SCTL_AMD_LROW(double, e.lists_f64, 0, 0) SCTL_AMD_LROW(double, e.lists_f64, 1, 1) SCTL_AMD_LROW(double, e.lists_f64, 2, 2)
+  SCTL_AMD_LROW(float, e.lists_f32, 0, 0) SCTL_AMD_LROW(float, e.lists_f32, 1, 1) SCTL_AMD_LROW(float, e.lists_f32, 2, 1)
+#undef SCTL_AMD_LROW
   return e;
 }
 

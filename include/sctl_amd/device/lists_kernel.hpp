@@ -1,0 +1,164 @@
+// Batched list evaluation for gfx950: MANY small (target range x source range) direct sums in ONE launch — the near-field
+// (P2P / U-list) shape of a tree code.  PVFMM calls the kernel once per (target box, source box) pair through
+// pvfmm::GenericKernel<PVFMMKernelFn_<Ker>> (reference include/sctl/fmm-wrapper.txx:756-786); a GPU cannot afford a launch per
+// box pair (a leaf holds 1-500 points), so the host groups the lists by target range and this kernel walks the groups.
+//
+// Work decomposition:
+//   * a work item = up to 64*T targets of one target range (leaf box) + ALL source ranges listed for that box; one wave64 per
+//     item (workgroup = one wave: nothing is shared between items, so there is no reason to couple their schedules);
+//   * every target is owned by exactly one item, so sums are accumulated in registers in list order and written once:
+//     deterministic, no atomics, no partial-sum workspace;
+//   * the item's source ranges are streamed as ONE concatenated sequence through a 64-record LDS tile (a tile may span several
+//     small ranges: 27 neighbour boxes of 5 points fill three tiles, not 27); the next tile's sources are fetched into registers
+//     while the current tile is evaluated;
+//   * the pair evaluation is the kernel's own exact, masked pair() (a box interacts with itself: coincident points are the norm).
+#pragma once
+#include "eval_kernel.hpp"
+
+namespace sctl_amd {
+
+constexpr int kListWave = 64;    // lanes per workgroup of the list kernel
+constexpr int kListTile = 64;    // sources per LDS tile
+
+struct ListItem {       // one wave
+  int64_t t0;           // first target (point index)
+  int32_t nt;           // targets of this item, 1 .. 64*T
+  int32_t nranges;      // source ranges of the target box
+  int64_t first_range;  // index of the first one in the range array
+};
+struct ListRange {      // sources [s0, s0 + ns)
+  int64_t s0;
+  int64_t ns;
+};
+
+template <class R> struct ListArgs {
+  const ListItem* items;
+  const ListRange* ranges;
+  const R* xt;      // [Nt*3]
+  const R* xs;      // [Ns*3]
+  const R* xn;      // [Ns*ND] or null
+  const R* f;       // [Ns*K0]
+  R* v_trg;         // [Nt*K1], accumulated into
+  R scale;
+  KerCtx ctx;
+};
+
+template <class Ker, class R, int MODE, int T>
+__global__ void __launch_bounds__(kListWave) lists_kernel(const ListArgs<R> a) {
+  constexpr int K0 = Ker::K0, K1 = Ker::K1, ND = Ker::ND, NREC = Ker::NREC;
+  using V = typename VecOf<R>::type;
+  constexpr int VN = VecOf<R>::N;
+  constexpr int NV = (NREC + VN - 1) / VN;
+  constexpr int NRECP = NV * VN;
+  __shared__ V tile[kListTile * NV];
+  using KC = typename Ker::template Consts<R>;
+  __shared__ double kscratch[KC::LDS_DOUBLES > 0 ? KC::LDS_DOUBLES : 1];
+  const KC K(kscratch);
+
+  const int lane = threadIdx.x;
+  const ListItem it = a.items[blockIdx.x];
+  const ListRange* const rg = a.ranges + it.first_range;
+
+  R xt[T][3], acc[T][K1];
+#pragma unroll
+  for (int j = 0; j < T; j++) {
+    int tl = j * kListWave + lane;
+    if (tl >= it.nt) tl = it.nt - 1;      // idle lanes repeat the last target; never stored
+    const int64_t t = it.t0 + tl;
+#pragma unroll
+    for (int k = 0; k < 3; k++) xt[j][k] = a.xt[t * 3 + k];
+#pragma unroll
+    for (int k = 0; k < K1; k++) acc[j][k] = 0;
+  }
+
+  // cursor into the concatenated source sequence (wave-uniform): range r, offset o inside it
+  int r = 0;
+  int64_t o = 0;
+  R sx[3] = {0, 0, 0}, sn[3] = {0, 0, 0}, sf[K0];
+#pragma unroll
+  for (int k = 0; k < K0; k++) sf[k] = 0;
+  // fetch the next (up to) 64 sources of the sequence into registers, lane i the i-th of them; returns how many
+  auto fetch = [&]() -> int {
+    int fill = 0;
+    int64_t mine = -1;
+    while (fill < kListTile && r < it.nranges) {
+      const int64_t left = rg[r].ns - o;
+      const int take = (left < (int64_t)(kListTile - fill)) ? (int)left : (kListTile - fill);
+      if (lane >= fill && lane < fill + take) mine = rg[r].s0 + o + (lane - fill);
+      fill += take;
+      o += take;
+      if (o >= rg[r].ns) { r++; o = 0; }
+    }
+    if (mine >= 0) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) sx[k] = a.xs[mine * 3 + k];
+#pragma unroll
+      for (int k = 0; k < ND; k++) sn[k] = a.xn[mine * ND + k];
+#pragma unroll
+      for (int k = 0; k < K0; k++) sf[k] = a.f[mine * K0 + k];
+    }
+    return fill;
+  };
+
+  int ns = fetch();
+  while (ns > 0) {
+    __syncthreads();   // previous tile fully consumed
+    if (lane < ns) {
+      R rec[NRECP] = {};
+      Ker::template pack<R>(rec, sx, sn, sf);
+#pragma unroll
+      for (int v = 0; v < NV; v++) {
+        V w;
+#pragma unroll
+        for (int e = 0; e < VN; e++) w[e] = rec[v * VN + e];
+        tile[lane * NV + v] = w;
+      }
+    }
+    const int ns_cur = ns;
+    ns = fetch();      // loads for the next tile are in flight during this tile's arithmetic
+    __syncthreads();
+
+    auto run_tile = [&](auto variant_tag) {
+      constexpr bool VARIANT = decltype(variant_tag)::value;
+      auto one_source = [&](int s) {
+        R rec[NRECP];
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+          const V w = tile[s * NV + v];
+#pragma unroll
+          for (int e = 0; e < VN; e++) rec[v * VN + e] = w[e];
+        }
+#pragma unroll
+        for (int j = 0; j < T; j++) {
+          const R d[3] = {xt[j][0] - rec[0], xt[j][1] - rec[1], xt[j][2] - rec[2]};
+          if constexpr (KC::HAS_VARIANT) Ker::template pair<R, MODE, true, VARIANT>(acc[j], d, rec, a.ctx, K);
+          else Ker::template pair<R, MODE, true>(acc[j], d, rec, a.ctx, K);
+        }
+      };
+      if (ns_cur == kListTile) {
+#pragma unroll UnrollOf<T, Ker::K1>::value
+        for (int s = 0; s < kListTile; s++) one_source(s);
+      } else {
+        for (int s = 0; s < ns_cur; s++) one_source(s);
+      }
+    };
+    if constexpr (KC::HAS_VARIANT) {   // a launch-uniform special case of the kernel (Helmholtz: real wavenumber) has its own loop
+      if (K.variant(a.ctx)) run_tile(std::true_type());
+      else run_tile(std::false_type());
+    } else {
+      run_tile(std::false_type());
+    }
+  }
+
+#pragma unroll
+  for (int j = 0; j < T; j++) {
+    const int tl = j * kListWave + lane;
+    if (tl < it.nt) {
+      const int64_t t = it.t0 + tl;
+#pragma unroll
+      for (int k = 0; k < K1; k++) a.v_trg[t * K1 + k] += acc[j][k] * a.scale;   // generic-kernel.txx:184
+    }
+  }
+}
+
+}  // namespace sctl_amd

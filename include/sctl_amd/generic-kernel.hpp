@@ -48,7 +48,8 @@ template <class uKernel> class GenericKernel : public uKernel {
 
   // Device kernel id of this functor, or a negative value when libsctl_amd.so does not implement it.
   static int DeviceKernelId() {
-    static const int id = sctl_amd_kernel_id(uKernel::Name().c_str());
+    static int id = -1;       // only a hit is cached: a plugin may register this functor after the first query
+    if (id < 0) id = sctl_amd_kernel_id(uKernel::Name().c_str());
     return id;
   }
   static bool IsSupported() { return DeviceKernelId() >= 0; }

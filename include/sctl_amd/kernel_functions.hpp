@@ -16,18 +16,22 @@ namespace sctl_amd {
 
 template <class Real> inline constexpr Real const_pi() { return (Real)3.141592653589793238462643383279502884L; }
 
-namespace kernel_impl {
-
+// Host-side descriptor of a kernel functor: what the reference deduces from uKerMatrix's signature, spelled out.  Also the way
+// to declare a USER-DEFINED functor whose device form was registered by a plugin (include/sctl_amd/device/kernel_plugin.hpp):
+//     namespace my { SCTL_AMD_UKERNEL(Yukawa3D_FxU_, "Yukawa3D-FxU", 1, 1, 0, 10, 8, 1 / (4 * sctl_amd::const_pi<Real>())); }
+//     using Yukawa3D_FxU = sctl_amd::GenericKernel<my::Yukawa3D_FxU_>;        // Eval / KernelMatrix / ParticleFMM / BoundaryIntegralOp
 #define SCTL_AMD_UKERNEL(STRUCT, NAME, K0, K1, ND, NFLOPS, CTXB, SCALE_EXPR)                          \
   struct STRUCT {                                                                                     \
-    static constexpr Integer SRC_DIM = K0, TRG_DIM = K1, NORMAL_DIM = ND, CTX_BYTES = CTXB;           \
+    static constexpr ::sctl_amd::Integer SRC_DIM = K0, TRG_DIM = K1, NORMAL_DIM = ND, CTX_BYTES = CTXB; \
     static const std::string& Name() {                                                                \
       static const std::string name = NAME;                                                           \
       return name;                                                                                    \
     }                                                                                                 \
-    static constexpr Integer FLOPS() { return NFLOPS; }                                               \
+    static constexpr ::sctl_amd::Integer FLOPS() { return NFLOPS; }                                   \
     template <class Real> static constexpr Real uKerScaleFactor() { return SCALE_EXPR; }              \
   }
+
+namespace kernel_impl {
 
 SCTL_AMD_UKERNEL(Laplace3D_FxU, "Laplace3D-FxU", 1, 1, 0, 6, 0, 1 / (4 * const_pi<Real>()));      // kernel_functions.hpp:15-31
 SCTL_AMD_UKERNEL(Laplace3D_DxU, "Laplace3D-DxU", 1, 1, 3, 14, 0, 1 / (4 * const_pi<Real>()));     // :33-51
@@ -42,7 +46,6 @@ SCTL_AMD_UKERNEL(Laplace3D_FDxUdU, "Laplace3D-FDxUdU", 2, 4, 3, 28, 0, 1 / (4 * 
 // new: exp(ikr)/(4 pi r); context = {Re k, Im k} as two doubles (SetCtxPtr(double[2]))
 SCTL_AMD_UKERNEL(Helmholtz3D_FxU, "Helmholtz3D-FxU", 2, 2, 0, 16, 16, 1 / (4 * const_pi<Real>()));
 
-#undef SCTL_AMD_UKERNEL
 }  // namespace kernel_impl
 
 // Notation (kernel_functions.hpp:202-214): F = single-layer source, D = double-layer source, U = potential, dU = gradient

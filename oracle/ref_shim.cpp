@@ -66,6 +66,21 @@ struct Helmholtz3D_FxU {    // exp(ikr)/r, complex k = ctx[0] + i ctx[1] (two do
     u[1][0] = VecType::Zero() - amp*sn; u[1][1] = amp*cs;
   }
 };
+
+// A functor that is NOT built into libsctl_amd.so: tests/plugin/yukawa_kernel.hip implements it as a user plugin
+// (include/sctl_amd/device/kernel_plugin.hpp); this is the same functor written for the reference, the plugin's oracle.
+struct Yukawa3D_FxU {       // exp(-lambda r)/r, lambda = ctx[0] (one double)
+  static const std::string& Name() { static const std::string name = "Yukawa3D-FxU"; return name; }
+  static constexpr Integer FLOPS() { return 10; }
+  template <class Real> static constexpr Real uKerScaleFactor() { return 1 / (4 * sctl::const_pi<Real>()); }
+  template <Integer digits, class VecType> static void uKerMatrix(VecType (&u)[1][1], const VecType (&r)[3], const void* ctx_ptr) {
+    using Real = typename VecType::ScalarType;
+    const double lambda = *static_cast<const double*>(ctx_ptr);
+    VecType r2 = r[0]*r[0]+r[1]*r[1]+r[2]*r[2];
+    VecType rinv = sctl::approx_rsqrt<digits>(r2, r2 > VecType::Zero());
+    u[0][0] = sctl::approx_exp<digits>(r2*rinv*VecType((Real)(-lambda)))*rinv;
+  }
+};
 }  // namespace ref_ext
 
 namespace ref_ext {
@@ -147,7 +162,7 @@ template <class F> int dispatch(const char* name, F&& f) {
   CASE(KerOf<kernel_impl::Laplace3D_FxU>) CASE(KerOf<kernel_impl::Laplace3D_DxU>) CASE(KerOf<kernel_impl::Laplace3D_FxdU>)
   CASE(KerOf<kernel_impl::Stokes3D_FxU>) CASE(KerOf<kernel_impl::Stokes3D_DxU>) CASE(KerOf<kernel_impl::Stokes3D_FxT>)
   CASE(KerOf<kernel_impl::Stokes3D_FSxU>) CASE(KerOf<kernel_impl::Stokes3D_FxUP>)
-  CASE(KerOf<ref_ext::Laplace3D_FDxUdU>) CASE(KerOf<ref_ext::Helmholtz3D_FxU>)
+  CASE(KerOf<ref_ext::Laplace3D_FDxUdU>) CASE(KerOf<ref_ext::Helmholtz3D_FxU>) CASE(KerOf<ref_ext::Yukawa3D_FxU>)
 #undef CASE
   return -1;
 }

@@ -25,7 +25,9 @@ SYMBOLS = ["sctl_amd_version", "sctl_amd_last_error", "sctl_amd_device_count", "
            "sctl_amd_kernel_matrix_device", "sctl_amd_kernel_matrix_host", "sctl_amd_kernel_matrix_batch_host", "sctl_amd_counters", "sctl_amd_reset_counters", "sctl_amd_trim",
            "sctl_amd_eval_plan", "sctl_amd_eval_path", "sctl_amd_op_create", "sctl_amd_op_set_targets",
            "sctl_amd_op_set_sources", "sctl_amd_op_set_source_weights", "sctl_amd_op_set_target_normals", "sctl_amd_op_eval", "sctl_amd_op_destroy", "sctl_amd_near_create", "sctl_amd_near_apply_host",
-           "sctl_amd_near_apply_device", "sctl_amd_near_info", "sctl_amd_near_destroy"]
+           "sctl_amd_near_apply_device", "sctl_amd_near_info", "sctl_amd_near_destroy", "sctl_amd_num_kernels", "sctl_amd_register_kernel", "sctl_amd_load_plugin",
+           "sctl_amd_op_set_near", "sctl_amd_op_eval_potential", "sctl_amd_lists_create", "sctl_amd_lists_eval_device", "sctl_amd_lists_eval_host", "sctl_amd_lists_info", "sctl_amd_lists_destroy",
+           "sctl_amd_eval_lists_device", "sctl_amd_eval_lists_host"]
 
 
 class SctlAmdError(RuntimeError):
@@ -101,6 +103,17 @@ def lib():
     L.sctl_amd_op_eval.argtypes = [vp, vp, vp, ci, ci, vp, ci]
     L.sctl_amd_op_destroy.argtypes = [vp]
     L.sctl_amd_op_destroy.restype = None
+    L.sctl_amd_op_set_near.argtypes = [vp, ci, ci, i64, vp, vp, vp, vp, vp, vp, vp]
+    L.sctl_amd_op_eval_potential.argtypes = [vp, vp, vp, vp, ci, ci, vp, ci]
+    L.sctl_amd_load_plugin.argtypes = [C.c_char_p]
+    L.sctl_amd_lists_create.argtypes = [ci, ci, ci, i64, vp, vp, vp, vp, i64, i64, C.POINTER(vp)]
+    L.sctl_amd_lists_eval_device.argtypes = [vp, vp, vp, vp, vp, vp, ci, vp, ci, vp]
+    L.sctl_amd_lists_eval_host.argtypes = [vp, vp, vp, vp, vp, vp, ci, vp, ci]
+    L.sctl_amd_lists_info.argtypes = [vp, pi64, pi64, pi64, C.POINTER(ci)]
+    L.sctl_amd_lists_destroy.argtypes = [vp]
+    L.sctl_amd_lists_destroy.restype = None
+    L.sctl_amd_eval_lists_host.argtypes = [ci, ci, i64, vp, vp, vp, vp, i64, i64, vp, vp, vp, vp, vp, ci, vp, ci, ci]
+    L.sctl_amd_eval_lists_device.argtypes = [ci, ci, i64, vp, vp, vp, vp, i64, i64, vp, vp, vp, vp, vp, ci, vp, ci, vp]
     _LIB = L
     return L
 
@@ -121,9 +134,18 @@ def device_count():
 def kernel_id(name):
     """Device kernel id for a functor Name(), or raises KeyError (the 'is it supported' query)."""
     k = name if isinstance(name, int) else lib().sctl_amd_kernel_id(name.encode())
-    if k < 0 or k >= len(KERNEL_NAMES):
+    if k < 0 or k >= lib().sctl_amd_num_kernels():
         raise KeyError("kernel %r is not implemented on the device" % (name,))
     return k
+
+
+def load_plugin(path):
+    """dlopen a kernel plugin (a user functor compiled against include/sctl_amd/device/kernel_plugin.hpp): returns the names it registered."""
+    n0 = lib().sctl_amd_num_kernels()
+    rc = lib().sctl_amd_load_plugin(os.fspath(path).encode())
+    if rc < 0:
+        raise SctlAmdError("load_plugin(%s) failed with status %d: %s" % (path, rc, last_error()))
+    return [lib().sctl_amd_kernel_name(i).decode() for i in range(n0, n0 + rc)]
 
 
 def kernel_info(name):
@@ -377,6 +399,26 @@ class DirectOp:
                                       _np_ptr(v_trg, self.dtype, self.Nt * k1, "v_trg"), 1 if accumulate else 0, digits, cp, cb), "op_eval")
         return v_trg
 
+    def set_near(self, trg_dim, elem_nds_cnt, near_elem_cnt, K_near, near_scatter_index, near_trg_cnt, near_trg_dsp, K_near_cnt=None):
+        """Attach the near-field operator of the same BoundaryIntegralOp (the arrays of NearOp) for the current targets."""
+        i8 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.int64)
+        nds, near, kcnt, sc, tc, td = i8(elem_nds_cnt), i8(near_elem_cnt), i8(K_near_cnt), i8(near_scatter_index), i8(near_trg_cnt), i8(near_trg_dsp)
+        K = np.ascontiguousarray(K_near, dtype=self.dtype)
+        p = lambda a: None if a is None or a.size == 0 else a.ctypes.data_as(C.c_void_p)
+        _check(lib().sctl_amd_op_set_near(self._h, self.info["k0"], trg_dim, nds.size, p(nds), p(near), p(kcnt), p(K), p(sc), p(tc), p(td)), "op_set_near")
+        self._near_len, self._near_k1 = int(nds.sum()) * self.info["k0"], trg_dim
+
+    def eval_potential(self, v_src_far, f_near, v_trg=None, accumulate=False, digits=-1):
+        """Far field + attached near field in one pass over the devices (sctl_amd_op_eval_potential): ComputePotential."""
+        k1 = self._near_k1
+        if v_trg is None or v_trg.size != self.Nt * k1:
+            v_trg = np.zeros(self.Nt * k1, dtype=self.dtype)
+        keep, cp, cb = _ctx_blob(self.info, self.ctx)
+        _check(lib().sctl_amd_op_eval_potential(self._h, _np_ptr(v_src_far, self.dtype, self.Ns * self.info["k0"], "v_src_far"),
+                                                _np_ptr(f_near, self.dtype, self._near_len, "f_near"), _np_ptr(v_trg, self.dtype, self.Nt * k1, "v_trg"),
+                                                1 if accumulate else 0, digits, cp, cb), "op_eval_potential")
+        return v_trg
+
     def close(self):
         if self._h:
             lib().sctl_amd_op_destroy(self._h)
@@ -442,3 +484,71 @@ class NearOp:
             self.close()
         except Exception:
             pass
+
+
+class ListsPlan:
+    """Many (target range x source range) direct sums in one launch (sctl_amd_lists_*): the P2P / U-list shape of a tree code
+    (fmm-wrapper.txx:756-786).  Offsets and counts are in points; target ranges must be identical or disjoint."""
+
+    def __init__(self, name, dtype, trg_off, trg_cnt, src_off, src_cnt, Nt, Ns, device=0, ctx=None):
+        self.info = kernel_info(name)
+        self.dtype = np.dtype(dtype)
+        self.real = _real_of(dtype)
+        self.ctx, self.Nt, self.Ns, self.device = ctx, int(Nt), int(Ns), device
+        arrs = [np.ascontiguousarray(a, dtype=np.int64) for a in (trg_off, trg_cnt, src_off, src_cnt)]
+        if len({a.size for a in arrs}) != 1:
+            raise SctlAmdError("the four list arrays must have one entry per list")
+        p = lambda a: a.ctypes.data_as(C.c_void_p) if a.size else None
+        self._h = C.c_void_p()
+        _check(lib().sctl_amd_lists_create(self.info["id"], self.real, device, arrs[0].size, p(arrs[0]), p(arrs[1]), p(arrs[2]), p(arrs[3]), self.Nt, self.Ns,
+                                           C.byref(self._h)), "lists_create")
+        v = [C.c_int64() for _ in range(3)]
+        t = C.c_int()
+        _check(lib().sctl_amd_lists_info(self._h, C.byref(v[0]), C.byref(v[1]), C.byref(v[2]), C.byref(t)), "lists_info")
+        self.pairs, self.work_items, self.source_ranges, self.trg_per_lane = v[0].value, v[1].value, v[2].value, t.value
+
+    def eval_host(self, r_trg, r_src, n_src, v_src, v_trg=None, digits=-1):
+        """numpy arrays; v_trg of the right size is accumulated into, otherwise a fresh zeroed result is returned."""
+        dt, i = self.dtype, self.info
+        if v_trg is None or v_trg.size != self.Nt * i["k1"]:
+            v_trg = np.zeros(self.Nt * i["k1"], dtype=dt)
+        keep, cp, cb = _ctx_blob(i, self.ctx)
+        _check(lib().sctl_amd_lists_eval_host(self._h, _np_ptr(r_trg, dt, self.Nt * 3, "r_trg"), _np_ptr(r_src, dt, self.Ns * 3, "r_src"),
+                                              _np_ptr(n_src, dt, self.Ns * i["nd"], "n_src"), _np_ptr(v_src, dt, self.Ns * i["k0"], "v_src"),
+                                              _np_ptr(v_trg, dt, self.Nt * i["k1"], "v_trg"), digits, cp, cb), "lists_eval_host")
+        return v_trg
+
+    def eval_device(self, r_trg, r_src, n_src, v_src, v_trg=None, digits=-1, stream=None):
+        """torch CUDA tensors on the plan's device; enqueued on `stream` (default: torch's current stream); v_trg is accumulated into."""
+        import torch
+        i = self.info
+        tdt = torch.float64 if self.dtype == np.float64 else torch.float32
+        if v_trg is None or v_trg.numel() != self.Nt * i["k1"]:
+            v_trg = torch.zeros(self.Nt * i["k1"], dtype=tdt, device=r_trg.device)
+        keep, cp, cb = _ctx_blob(i, self.ctx)
+        with torch.cuda.device(r_trg.device):
+            st = stream if stream is not None else torch.cuda.current_stream()
+            _check(lib().sctl_amd_lists_eval_device(self._h, _t_ptr(r_trg, tdt, self.Nt * 3, "r_trg"), _t_ptr(r_src, tdt, self.Ns * 3, "r_src"),
+                                                    _t_ptr(n_src, tdt, self.Ns * i["nd"], "n_src"), _t_ptr(v_src, tdt, self.Ns * i["k0"], "v_src"),
+                                                    _t_ptr(v_trg, tdt, self.Nt * i["k1"], "v_trg"), digits, cp, cb, C.c_void_p(st.cuda_stream)), "lists_eval_device")
+        return v_trg
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().sctl_amd_lists_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def eval_lists_host(name, trg_off, trg_cnt, src_off, src_cnt, r_trg, r_src, n_src, v_src, v_trg=None, digits=-1, ctx=None, device=0):
+    """One-shot sctl_amd_eval_lists_host."""
+    plan = ListsPlan(name, r_trg.dtype, trg_off, trg_cnt, src_off, src_cnt, r_trg.size // 3, r_src.size // 3, device=device, ctx=ctx)
+    try:
+        return plan.eval_host(r_trg, r_src, n_src, v_src, v_trg, digits)
+    finally:
+        plan.close()

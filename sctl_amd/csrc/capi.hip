@@ -1,8 +1,9 @@
 // C ABI of libsctl_amd.so (include/sctl_amd.h): argument checks, launch planning, host<->device staging
 // and the one-process multi-GPU driver.  All arithmetic lives in eval_kernel.hpp / ukernels.hpp.
-#include "../../include/sctl_amd.h"
-#include "launch.hpp"
+#include "internal.hpp"
 #include "workspace.hpp"
+
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <atomic>
@@ -39,14 +40,59 @@ namespace {
     if (e_ != hipSuccess) return fail(SCTL_AMD_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
   } while (0)
 
-const KernelEntry* registry(int id) {
-  static const KernelEntry* tab[SCTL_AMD_NUM_KERNELS] = {
-      &entry_Laplace3D_FxU(),  &entry_Laplace3D_DxU(),  &entry_Laplace3D_FxdU(),   &entry_Stokes3D_FxU(),   &entry_Stokes3D_DxU(),
-      &entry_Stokes3D_FxT(),   &entry_Stokes3D_FSxU(),  &entry_Stokes3D_FxUP(),    &entry_Laplace3D_FDxUdU(), &entry_Helmholtz3D_FxU()};
-  return (id >= 0 && id < SCTL_AMD_NUM_KERNELS) ? tab[id] : nullptr;
+}  // namespace
+
+// ---- kernel registry: the ten built-in functors, then whatever plugins register (sctl_amd_register_kernel) --------------------
+namespace {
+constexpr int kMaxKernels = 256;
+struct Registry {
+  const KernelEntry* tab[kMaxKernels] = {};
+  std::atomic<int> n{0};
+  std::mutex mu;
+  Registry() {
+    const KernelEntry* builtin[SCTL_AMD_NUM_KERNELS] = {
+        &entry_Laplace3D_FxU(),  &entry_Laplace3D_DxU(),  &entry_Laplace3D_FxdU(),   &entry_Stokes3D_FxU(),   &entry_Stokes3D_DxU(),
+        &entry_Stokes3D_FxT(),   &entry_Stokes3D_FSxU(),  &entry_Stokes3D_FxUP(),    &entry_Laplace3D_FDxUdU(), &entry_Helmholtz3D_FxU()};
+    for (int i = 0; i < SCTL_AMD_NUM_KERNELS; i++) tab[i] = builtin[i];
+    n = SCTL_AMD_NUM_KERNELS;
+  }
+};
+Registry& reg() {
+  static Registry* r = new Registry;   // leaked on purpose: plugins may register from static initialisers in any order
+  return *r;
 }
+}  // namespace
+const KernelEntry* registry(int id) { return (id >= 0 && id < reg().n.load()) ? reg().tab[id] : nullptr; }
+int registry_size() { return reg().n.load(); }
+int registry_find(const char* name) {
+  if (!name) return SCTL_AMD_ERR_UNKNOWN_KERNEL;
+  const int n = reg().n.load();
+  for (int i = 0; i < n; i++)
+    if (!std::strcmp(reg().tab[i]->name, name)) return i;
+  return SCTL_AMD_ERR_UNKNOWN_KERNEL;
+}
+int registry_add(const KernelEntry& e, std::string* why) {
+  Registry& r = reg();
+  std::lock_guard<std::mutex> lock(r.mu);
+  const int n = r.n.load();
+  for (int i = 0; i < n; i++)
+    if (!std::strcmp(r.tab[i]->name, e.name)) { *why = std::string("a kernel called '") + e.name + "' is already registered"; return SCTL_AMD_ERR_BAD_ARGUMENT; }
+  if (n >= kMaxKernels) { *why = "kernel registry is full"; return SCTL_AMD_ERR_BAD_ARGUMENT; }
+  KernelEntry* copy = new KernelEntry(e);          // lives as long as the process (ids are never recycled)
+  char* name = new char[std::strlen(e.name) + 1];
+  std::strcpy(name, e.name);
+  copy->name = name;
+  copy->id = n;
+  r.tab[n] = copy;
+  r.n.store(n + 1);
+  return n;
+}
+namespace {
 
 std::atomic<int64_t> g_pairs{0}, g_flops{0};
+}  // namespace
+void count_work(int64_t pairs, const KernelEntry& k) { g_pairs += pairs; g_flops += pairs * k.flops; }
+namespace {
 
 template <class R> EvalLaunch<R> pick_eval(const KernelEntry& k, int mode, int t);
 template <> EvalLaunch<double> pick_eval<double>(const KernelEntry& k, int mode, int t) { return k.eval_f64[mode][t]; }
@@ -55,11 +101,13 @@ template <class R> MatrixLaunch<R> pick_matrix(const KernelEntry& k, int mode);
 template <> MatrixLaunch<double> pick_matrix<double>(const KernelEntry& k, int mode) { return k.matrix_f64[mode]; }
 template <> MatrixLaunch<float> pick_matrix<float>(const KernelEntry& k, int mode) { return k.matrix_f32[mode]; }
 
+}  // namespace
 int device_count_quiet() {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
   return n;
 }
+namespace {
 
 int cu_count() {   // CUs of the current device; 256 (MI355X) when planning without a device
   static std::once_flag once;
@@ -75,6 +123,7 @@ int cu_count() {   // CUs of the current device; 256 (MI355X) when planning with
 
 // digits -> refinement mode of ukernels.hpp rsqrt_masked (the reference maps digits to Newton iteration
 // counts at compile time, intrin-wrapper.hpp:3025-3050; -1 and >= 16 mean full precision, generic-kernel.txx:46-77)
+}  // namespace
 int mode_for(int real, int digits) {
   if (real == SCTL_AMD_F64) {
     if (digits < 0 || digits > 14) return 2;
@@ -82,6 +131,7 @@ int mode_for(int real, int digits) {
   }
   return (digits < 0 || digits <= 7) ? 0 : 1;
 }
+namespace {
 
 struct Plan {
   int t_idx;        // index into kTvalues
@@ -132,11 +182,13 @@ int check_common(const KernelEntry* k, int real, int64_t Nt, int64_t Ns, const v
   return SCTL_AMD_OK;
 }
 
+}  // namespace
 KerCtx make_ctx(const KernelEntry& k, const void* ctx) {
   KerCtx c{};
   if (k.ctx_bytes > 0) std::memcpy(c.v, ctx, (size_t)k.ctx_bytes);
   return c;
 }
+namespace {
 
 // Tile-centred fast path (centered_kernel.hpp): Laplace single layer (fp64 and fp32) on problems large enough to amortise the
 // Morton sort of the targets.  SCTL_AMD_CENTERED=0 in the environment forces the exact kernel (used for A/B checks).
@@ -383,6 +435,12 @@ struct sctl_amd_op {
   // density of the whole set (what the tile-centred path needs); perm[i] = caller's index of sorted target i
   std::vector<int64_t> perm;
   bool have_weights = false, have_trg_normals = false;   // far-field pre/post steps on the device (sctl_amd_op_set_source_weights / _target_normals)
+  // BoundaryIntegralOp near field attached to this operator (sctl_amd_op_set_near): one sub-operator per device, holding the columns
+  // (near targets) of every element block that fall into that device's target slab, so far + near are added ON the device
+  std::vector<sctl_amd_near*> near;
+  std::vector<void*> near_f;      // device copy of the near density (element nodes x SrcDim), one per device
+  int64_t near_f_len = 0;
+  int near_trg_dim = 0;
 };
 
 namespace sctl_amd {
@@ -446,11 +504,38 @@ int sctl_amd_version(void) { return SCTL_AMD_VERSION; }
 const char* sctl_amd_last_error(void) { return g_err.c_str(); }
 int sctl_amd_device_count(void) { return device_count_quiet(); }
 
-int sctl_amd_kernel_id(const char* name) {
-  if (!name) return SCTL_AMD_ERR_UNKNOWN_KERNEL;
-  for (int i = 0; i < SCTL_AMD_NUM_KERNELS; i++)
-    if (!std::strcmp(registry(i)->name, name)) return i;
-  return SCTL_AMD_ERR_UNKNOWN_KERNEL;
+int sctl_amd_kernel_id(const char* name) { return registry_find(name); }
+int sctl_amd_num_kernels(void) { return registry_size(); }
+
+int sctl_amd_register_kernel(const sctl_amd_kernel_desc* d) {
+  if (!d) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "null kernel descriptor");
+  if (d->abi_version != SCTL_AMD_DEVICE_ABI || d->desc_bytes != (int)sizeof(sctl_amd_kernel_desc) || d->entry_bytes != (int)sizeof(KernelEntry))
+    return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "kernel plugin was compiled with other device headers (ABI " + std::to_string(d->abi_version) + ", library " +
+                                              std::to_string(SCTL_AMD_DEVICE_ABI) + "): rebuild it against this library's include/sctl_amd/device");
+  const KernelEntry* e = (const KernelEntry*)d->launch_table;
+  if (!e || !d->name || !e->name || std::strcmp(e->name, d->name) != 0 || !d->name[0]) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "kernel descriptor without a name or launch table");
+  if (e->k0 != d->src_dim || e->k1 != d->trg_dim || e->nd != d->normal_dim || e->flops != d->flops || e->ctx_bytes != d->ctx_bytes || e->scale != d->scale)
+    return fail(SCTL_AMD_ERR_BAD_ARGUMENT, std::string("descriptor of '") + d->name + "' disagrees with its launch table");
+  if (e->k0 < 1 || e->k1 < 1 || (e->nd != 0 && e->nd != 3) || e->ctx_bytes < 0 || e->ctx_bytes > (int)sizeof(KerCtx))
+    return fail(SCTL_AMD_ERR_BAD_ARGUMENT, std::string("kernel '") + d->name + "': dimensions or context size out of range");
+  for (int m = 0; m < kNumMode; m++) {
+    if (!(e->acc_factor[m] > 0) || !e->matrix_f64[m] || !e->matrix_f32[m] || !e->matrix_batch_f64[m] || !e->matrix_batch_f32[m] || !e->lists_f64[m][0] ||
+        !e->lists_f64[m][1] || !e->lists_f32[m][0] || !e->lists_f32[m][1])
+      return fail(SCTL_AMD_ERR_BAD_ARGUMENT, std::string("kernel '") + d->name + "': incomplete launch table");
+    for (int t = 0; t < kNumT; t++)
+      if (!e->eval_f64[m][t] || !e->eval_f32[m][t]) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, std::string("kernel '") + d->name + "': incomplete launch table");
+  }
+  std::string why;
+  const int id = registry_add(*e, &why);
+  return id >= 0 ? id : fail(id, why);
+}
+
+int sctl_amd_load_plugin(const char* path) {
+  if (!path || !path[0]) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "empty plugin path");
+  const int before = registry_size();
+  void* h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+  if (!h) { const char* e = dlerror(); return fail(SCTL_AMD_ERR_BAD_ARGUMENT, std::string("cannot load kernel plugin: ") + (e ? e : path)); }
+  return registry_size() - before;   // the handle is kept open on purpose: registered launch pointers point into the plugin
 }
 const char* sctl_amd_kernel_name(int kernel) {
   const KernelEntry* k = registry(kernel);
@@ -664,8 +749,10 @@ int sctl_amd_op_create(int kernel, int real, const int* devices, int n_devices, 
   return SCTL_AMD_OK;
 }
 
+static void op_release_near(sctl_amd_op* op);
 void sctl_amd_op_destroy(sctl_amd_op* op) {
   if (!op) return;
+  op_release_near(op);
   RestoreDevice restore;
   const int avail = device_count_quiet();
   for (OpDevice& d : op->devs) {
@@ -684,6 +771,7 @@ int sctl_amd_op_set_targets(sctl_amd_op* op, int64_t Nt, const void* r_trg) {
   const int G = (int)op->devs.size();
   op->Nt = Nt;
   op->have_trg_normals = false;   // normals belong to a target set: set them again after new targets
+  op_release_near(op);            // and so does an attached near-field operator (its columns are target slabs)
   int g = 0;
   for (OpDevice& d : op->devs) { d.t0 = Nt * g / G; d.t1 = Nt * (g + 1) / G; g++; }   // fmm-wrapper.txx:507
   // several devices, or a kernel with a tile-centred path: the targets are kept in Morton order (coordinates gathered into sorted
@@ -771,24 +859,31 @@ int sctl_amd_op_set_target_normals(sctl_amd_op* op, const void* n_trg) {
   return rc;
 }
 
-int sctl_amd_op_eval(sctl_amd_op* op, const void* v_src, void* v_trg, int accumulate, int digits, const void* ctx, int ctx_bytes) {
+// far field (+ the attached near field when f_near != nullptr) of one density, potential back to the host once
+static int op_eval_impl(sctl_amd_op* op, const void* v_src, const void* f_near, void* v_trg, int accumulate, int digits, const void* ctx, int ctx_bytes) {
   if (!op) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "null handle");
   const KernelEntry& k = *op->k;
+  if (f_near && op->near.empty()) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "no near-field operator attached: call sctl_amd_op_set_near first");
+  if (f_near && op->near_trg_dim != (op->have_trg_normals ? k.k1 / 3 : k.k1))
+    return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "the attached near-field operator has another potential dimension than the far field delivers");
   if (k.ctx_bytes != 0 && (ctx_bytes != k.ctx_bytes || !ctx))
     return fail(SCTL_AMD_ERR_BAD_CONTEXT, std::string(k.name) + " needs a context blob of " + std::to_string(k.ctx_bytes) + " bytes");
   if ((op->Ns > 0 && !v_src) || (op->Nt > 0 && !v_trg)) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "null density or potential array");
   const size_t rs = (op->real == SCTL_AMD_F64) ? 8 : 4;
   const int64_t Ns = op->Ns;
+  const size_t near_bytes = f_near ? (size_t)op->near_f_len * rs : 0;
   return op_for_each_device(op, [&](OpDevice& d) -> int {
     const int64_t nt = d.t1 - d.t0;
     const size_t vbytes = (size_t)nt * k.k1 * rs;
     if (nt == 0) return SCTL_AMD_OK;
+    const size_t g = (size_t)(&d - op->devs.data());
     DeviceScope dev_scope_8(d.device);
     HIP_TRY(dev_scope_8.err);
     HIP_TRY(grow(&d.f, &d.cap_f, (size_t)Ns * k.k0 * rs));
     HIP_TRY(grow(&d.v, &d.cap_v, vbytes));
-    HIP_TRY(d.stage.reserve(pad256((size_t)Ns * k.k0 * rs) + pad256(vbytes)));
+    HIP_TRY(d.stage.reserve(pad256((size_t)Ns * k.k0 * rs) + pad256(near_bytes) + pad256(vbytes)));
     HIP_TRY(upload(d.f, v_src, (size_t)Ns * k.k0 * rs, d.stage, d.st));
+    if (near_bytes) HIP_TRY(upload(op->near_f[g], f_near, near_bytes, d.stage, d.st));
     if (op->have_weights) {   // density x quadrature weights (boundary_integral.txx:1040-1052)
       const unsigned nb = (unsigned)((Ns * k.k0 + kBlock - 1) / kBlock);
       if (op->real == SCTL_AMD_F64) hipLaunchKernelGGL((scale_density_kernel<double>), dim3(nb), dim3(kBlock), 0, d.st, (double*)d.f, (const double*)d.w, Ns, k.k0);
@@ -796,8 +891,9 @@ int sctl_amd_op_eval(sctl_amd_op* op, const void* v_src, void* v_trg, int accumu
       HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipMemsetAsync(d.v, 0, vbytes, d.st));
-    int rc;
-    if (op->real == SCTL_AMD_F64)
+    int rc = SCTL_AMD_OK;
+    if (Ns == 0) {}           // no far-field sources: the potential is the near field alone
+    else if (op->real == SCTL_AMD_F64)
       rc = eval_device_t<double>(k, op->real, nt, Ns, (const double*)d.xt, (const double*)d.xs, (const double*)d.xn, (const double*)d.f, (double*)d.v,
                                  digits, ctx, d.st, op->perm.empty() ? 0 : op->Nt, !op->perm.empty());
     else
@@ -805,7 +901,7 @@ int sctl_amd_op_eval(sctl_amd_op* op, const void* v_src, void* v_trg, int accumu
                                 ctx, d.st, op->perm.empty() ? 0 : op->Nt, !op->perm.empty());
     if (rc) return rc;
     int k1 = k.k1;            // components per target that go back to the host
-    const void* result = d.v;
+    void* result = d.v;
     if (op->have_trg_normals) {   // contract the last index with the target normal (boundary_integral.txx:1060-1071): 3x less D2H
       k1 = k.k1 / 3;
       HIP_TRY(grow(&d.u, &d.cap_u, (size_t)nt * k1 * rs));
@@ -814,6 +910,10 @@ int sctl_amd_op_eval(sctl_amd_op* op, const void* v_src, void* v_trg, int accumu
       else hipLaunchKernelGGL((normal_dot_kernel<float>), dim3(nb), dim3(kBlock), 0, d.st, (const float*)d.v, (const float*)d.nt, (float*)d.u, nt, k1);
       HIP_TRY(hipGetLastError());
       result = d.u;
+    }
+    if (f_near && op->near[g]) {   // the near-zone correction of this slab's targets, added where the far field lies (boundary_integral.txx:608-614)
+      rc = sctl_amd_near_apply_device(op->near[g], op->near_f[g], result, d.st);
+      if (rc) return rc;
     }
     const size_t obytes = (size_t)nt * k1 * rs;
     char* dst = (char*)v_trg + (size_t)d.t0 * k1 * rs;
@@ -840,6 +940,120 @@ int sctl_amd_op_eval(sctl_amd_op* op, const void* v_src, void* v_trg, int accumu
     else { float* o = (float*)dst; const float* s = (const float*)out; for (int64_t i = 0; i < n; i++) o[i] += s[i]; }
     return SCTL_AMD_OK;
   });
+}
+
+int sctl_amd_op_eval(sctl_amd_op* op, const void* v_src, void* v_trg, int accumulate, int digits, const void* ctx, int ctx_bytes) {
+  return op_eval_impl(op, v_src, nullptr, v_trg, accumulate, digits, ctx, ctx_bytes);
+}
+
+int sctl_amd_op_eval_potential(sctl_amd_op* op, const void* v_src_far, const void* f_near, void* v_trg, int accumulate, int digits, const void* ctx,
+                               int ctx_bytes) {
+  if (op && op->near_f_len > 0 && !f_near) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "null near-field density");
+  static const char nothing = 0;   // an operator without element nodes still takes the near path (which then adds nothing)
+  return op_eval_impl(op, v_src_far, (op && op->near_f_len == 0) ? (const void*)&nothing : f_near, v_trg, accumulate, digits, ctx, ctx_bytes);
+}
+
+static void op_release_near(sctl_amd_op* op) {
+  RestoreDevice restore;
+  for (size_t g = 0; g < op->near.size(); g++) {
+    if (op->near[g]) sctl_amd_near_destroy(op->near[g]);
+    if (g < op->near_f.size() && op->near_f[g] && hipSetDevice(op->devs[g].device) == hipSuccess) (void)hipFree(op->near_f[g]);
+  }
+  op->near.clear();
+  op->near_f.clear();
+  op->near_f_len = 0;
+  op->near_trg_dim = 0;
+}
+
+int sctl_amd_op_set_near(sctl_amd_op* op, int src_dim, int trg_dim, int64_t Nelem, const int64_t* elem_nds_cnt, const int64_t* near_elem_cnt,
+                         const int64_t* K_near_cnt, const void* K_near, const int64_t* near_scatter_index, const int64_t* near_trg_cnt,
+                         const int64_t* near_trg_dsp) {
+  if (!op) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "null handle");
+  op_release_near(op);
+  if (Nelem == 0 && !elem_nds_cnt) return SCTL_AMD_OK;   // detach
+  if (src_dim != op->k->k0) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "near-field operator: src_dim differs from the kernel's SrcDim");
+  if (Nelem < 0 || trg_dim < 1 || (Nelem > 0 && (!elem_nds_cnt || !near_elem_cnt)) || (op->Nt > 0 && (!near_trg_cnt || !near_trg_dsp)))
+    return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "near-field operator: bad sizes or null count arrays");
+  const int64_t Nt = op->Nt;
+  const size_t rs = (op->real == SCTL_AMD_F64) ? 8 : 4;
+  const int G = (int)op->devs.size();
+  // per-element displacements, and for every near entry (element-major) the target it belongs to
+  std::vector<int64_t> near_dsp((size_t)Nelem + 1, 0), k_dsp((size_t)Nelem + 1, 0);
+  int64_t f_len = 0;
+  for (int64_t e = 0; e < Nelem; e++) {
+    if (elem_nds_cnt[e] < 0 || near_elem_cnt[e] < 0) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "negative element count");
+    const int64_t kc = K_near_cnt ? K_near_cnt[e] : elem_nds_cnt[e] * near_elem_cnt[e];
+    if (kc != 0 && kc != elem_nds_cnt[e] * near_elem_cnt[e]) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "K_near_cnt[e] must be 0 or elem_nds_cnt[e] * near_elem_cnt[e]");
+    near_dsp[(size_t)e + 1] = near_dsp[(size_t)e] + near_elem_cnt[e];
+    k_dsp[(size_t)e + 1] = k_dsp[(size_t)e] + kc;
+    f_len += elem_nds_cnt[e] * src_dim;
+  }
+  const int64_t n_near = near_dsp[(size_t)Nelem];
+  if (n_near > 0 && !near_scatter_index) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "null near_scatter_index");
+  if (k_dsp[(size_t)Nelem] > 0 && !K_near) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "null K_near");
+  std::vector<int64_t> trg_of_entry((size_t)n_near, -1);
+  for (int64_t i = 0; i < Nt; i++) {
+    if (near_trg_cnt[i] < 0 || near_trg_dsp[i] < 0 || near_trg_dsp[i] + near_trg_cnt[i] > n_near) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "near_trg_dsp/cnt outside the near list");
+    for (int64_t p = near_trg_dsp[i]; p < near_trg_dsp[i] + near_trg_cnt[i]; p++) {
+      const int64_t entry = near_scatter_index[p];
+      if (entry < 0 || entry >= n_near || trg_of_entry[(size_t)entry] >= 0) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "near_scatter_index is not a permutation of the near list");
+      trg_of_entry[(size_t)entry] = i;
+    }
+  }
+  for (int64_t q = 0; q < n_near; q++)
+    if (trg_of_entry[(size_t)q] < 0) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "a near-list entry belongs to no target");
+  // slot of every caller target in the operator's own (Morton) target order
+  std::vector<int64_t> slot((size_t)Nt);
+  for (int64_t i = 0; i < Nt; i++) slot[op->perm.empty() ? (size_t)i : (size_t)op->perm[(size_t)i]] = i;
+  op->near.assign((size_t)G, nullptr);
+  op->near_f.assign((size_t)G, nullptr);
+  op->near_f_len = f_len;
+  op->near_trg_dim = trg_dim;
+  const char* Kh = (const char*)K_near;
+  for (int g = 0; g < G; g++) {
+    const OpDevice& d = op->devs[(size_t)g];
+    const int64_t nt_g = d.t1 - d.t0;
+    // this device's share: per element the columns (near targets) whose target lies in [t0, t1), in their original order
+    std::vector<int64_t> cnt_g((size_t)Nelem, 0), kcnt_g((size_t)Nelem, 0), new_id((size_t)n_near, -1);
+    std::vector<char> Kg;
+    int64_t n_g = 0;
+    for (int64_t e = 0; e < Nelem; e++) {
+      const int64_t c0 = near_dsp[(size_t)e], nc = near_elem_cnt[e], rows = elem_nds_cnt[e] * src_dim;
+      const bool has_matrix = (k_dsp[(size_t)e + 1] > k_dsp[(size_t)e]);
+      std::vector<int64_t> cols;
+      for (int64_t j = 0; j < nc; j++) {
+        const int64_t s = slot[(size_t)trg_of_entry[(size_t)(c0 + j)]];
+        if (s >= d.t0 && s < d.t1) { cols.push_back(j); new_id[(size_t)(c0 + j)] = n_g++; }
+      }
+      cnt_g[(size_t)e] = (int64_t)cols.size();
+      if (!has_matrix || cols.empty() || rows == 0) continue;
+      kcnt_g[(size_t)e] = elem_nds_cnt[e] * (int64_t)cols.size();
+      const size_t row_in = (size_t)nc * trg_dim * rs, piece = (size_t)trg_dim * rs;
+      const char* blk = Kh + (size_t)k_dsp[(size_t)e] * src_dim * trg_dim * rs;
+      const size_t at = Kg.size();
+      Kg.resize(at + (size_t)rows * cols.size() * piece);
+      char* out = Kg.data() + at;
+      for (int64_t r = 0; r < rows; r++)
+        for (int64_t j : cols) { std::memcpy(out, blk + (size_t)r * row_in + (size_t)j * piece, piece); out += piece; }
+    }
+    std::vector<int64_t> sc_g((size_t)n_g), tc_g((size_t)nt_g, 0), td_g((size_t)nt_g, 0);
+    int64_t p_g = 0;
+    for (int64_t s = d.t0; s < d.t1; s++) {   // targets in slab order, their entries in the caller's order
+      const int64_t i = op->perm.empty() ? s : op->perm[(size_t)s];
+      td_g[(size_t)(s - d.t0)] = p_g;
+      tc_g[(size_t)(s - d.t0)] = near_trg_cnt[i];
+      for (int64_t p = near_trg_dsp[i]; p < near_trg_dsp[i] + near_trg_cnt[i]; p++) sc_g[(size_t)p_g++] = new_id[(size_t)near_scatter_index[p]];
+    }
+    if (nt_g == 0) continue;
+    int rc = sctl_amd_near_create(op->real, d.device, Nelem, src_dim, trg_dim, elem_nds_cnt, cnt_g.data(), kcnt_g.data(), Kg.empty() ? nullptr : Kg.data(), nt_g,
+                                  sc_g.empty() ? nullptr : sc_g.data(), tc_g.data(), td_g.data(), &op->near[(size_t)g]);
+    if (rc == SCTL_AMD_OK && f_len > 0) {
+      DeviceScope scope(d.device);
+      if (scope.err != hipSuccess || hipMalloc(&op->near_f[(size_t)g], (size_t)f_len * rs) != hipSuccess) rc = fail(SCTL_AMD_ERR_HIP, "cannot allocate the near-field density on device " + std::to_string(d.device));
+    }
+    if (rc != SCTL_AMD_OK) { const std::string msg = g_err; op_release_near(op); g_err = msg; return rc; }
+  }
+  return SCTL_AMD_OK;
 }
 
 void sctl_amd_counters(int64_t* pair_interactions, int64_t* sctl_flops) {

@@ -2,7 +2,7 @@
 // (rocPRIM radix sort of 63-bit keys), evaluate on the sorted order, scatter-add the result back.  Everything is enqueued
 // on the caller's stream; temporaries are carved out of the stream's scratch block (workspace.hpp).
 #include "centered_kernel.hpp"
-#include "launch.hpp"
+#include <sctl_amd/device/launch.hpp>
 #include "workspace.hpp"
 
 #include <cstdlib>

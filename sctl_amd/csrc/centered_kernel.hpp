@@ -17,7 +17,7 @@
 // no per-pair branch.  The host side (centered.hip) Morton-sorts the targets first so that the 128 targets of a wave are
 // compact; results are scattered back through the permutation.
 #pragma once
-#include "eval_kernel.hpp"
+#include <sctl_amd/device/eval_kernel.hpp>
 
 namespace sctl_amd {
 

@@ -1,5 +1,5 @@
 // Instantiations of the evaluation and operator kernels for Laplace3D_DxU (see launch.hpp).
-#include "launch.hpp"
+#include <sctl_amd/device/launch.hpp>
 namespace sctl_amd {
 const KernelEntry& entry_Laplace3D_DxU() {
   static const KernelEntry e = make_entry<Laplace3D_DxU>(0);

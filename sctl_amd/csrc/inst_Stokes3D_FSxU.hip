@@ -1,5 +1,5 @@
 // Instantiations of the evaluation and operator kernels for Stokes3D_FSxU (see launch.hpp).
-#include "launch.hpp"
+#include <sctl_amd/device/launch.hpp>
 namespace sctl_amd {
 const KernelEntry& entry_Stokes3D_FSxU() {
   static const KernelEntry e = make_entry<Stokes3D_FSxU>(0);

@@ -1,0 +1,240 @@
+// Batched list evaluation (sctl_amd_lists_*, sctl_amd_eval_lists_*): the host side of include/sctl_amd/device/lists_kernel.hpp.
+// A plan validates the lists, groups them by target range (a leaf box and ALL the source boxes listed for it become the work of
+// whole waves), orders the work items by cost and keeps them on the device; an evaluation is ONE launch.
+#include "internal.hpp"
+#include "workspace.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+namespace sctl_amd {
+namespace {
+#define LISTS_TRY(expr)                                                                                             \
+  do {                                                                                                              \
+    hipError_t e_ = (expr);                                                                                         \
+    if (e_ != hipSuccess) return set_error(SCTL_AMD_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));    \
+  } while (0)
+}  // namespace
+}  // namespace sctl_amd
+
+struct sctl_amd_lists {
+  const sctl_amd::KernelEntry* k = nullptr;
+  int real = 0, device = 0, t_idx = 0;      // t_idx: 0 = one target per lane, 1 = two
+  int64_t Nt = 0, Ns = 0, nitems = 0, nranges = 0, pairs = 0;
+  void *d_items = nullptr, *d_ranges = nullptr;
+  // host-pointer evaluation: device copies of the caller's arrays and pinned staging, grown on demand
+  hipStream_t st = nullptr;
+  void* dbuf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t dcap[5] = {0, 0, 0, 0, 0};
+  char* pinned = nullptr;
+  size_t pinned_cap = 0;
+};
+
+using namespace sctl_amd;
+
+extern "C" {
+
+int sctl_amd_lists_create(int kernel, int real, int device, int64_t nlists, const int64_t* trg_off, const int64_t* trg_cnt, const int64_t* src_off,
+                          const int64_t* src_cnt, int64_t Nt, int64_t Ns, sctl_amd_lists** out) {
+  const KernelEntry* k = registry(kernel);
+  if (!k) return set_error(SCTL_AMD_ERR_UNKNOWN_KERNEL, "unknown kernel id");
+  if (real != SCTL_AMD_F64 && real != SCTL_AMD_F32) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "real must be SCTL_AMD_F64 or SCTL_AMD_F32");
+  if (!out || nlists < 0 || Nt < 0 || Ns < 0 || (nlists > 0 && (!trg_off || !trg_cnt || !src_off || !src_cnt)))
+    return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "null handle pointer, negative size or null list arrays");
+  for (int64_t l = 0; l < nlists; l++) {
+    if (trg_cnt[l] < 0 || src_cnt[l] < 0 || trg_off[l] < 0 || src_off[l] < 0 || trg_off[l] + trg_cnt[l] > Nt || src_off[l] + src_cnt[l] > Ns)
+      return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "list " + std::to_string(l) + " reaches outside the target or source arrays");
+  }
+  // group the lists by target range: stable sort by (first target, count) keeps the caller's order inside a group, which is
+  // the order the sources are summed in
+  std::vector<int64_t> order;
+  order.reserve((size_t)nlists);
+  for (int64_t l = 0; l < nlists; l++)
+    if (trg_cnt[l] > 0 && src_cnt[l] > 0) order.push_back(l);
+  std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return trg_off[a] != trg_off[b] ? trg_off[a] < trg_off[b] : trg_cnt[a] < trg_cnt[b]; });
+  struct Group { int64_t t0, nt, first_range, nranges, nsrc; };
+  std::vector<Group> groups;
+  std::vector<ListRange> ranges;
+  ranges.reserve(order.size());
+  int64_t pairs = 0, trg_in_groups = 0;
+  for (size_t i = 0; i < order.size(); i++) {
+    const int64_t l = order[i];
+    if (groups.empty() || groups.back().t0 != trg_off[l] || groups.back().nt != trg_cnt[l]) {
+      if (!groups.empty() && trg_off[l] < groups.back().t0 + groups.back().nt)
+        return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "the target ranges of lists " + std::to_string(order[i - 1]) + " and " + std::to_string(l) +
+                                                        " overlap without being equal: target ranges must be identical or disjoint");
+      groups.push_back(Group{trg_off[l], trg_cnt[l], (int64_t)ranges.size(), 0, 0});
+      trg_in_groups += trg_cnt[l];
+    }
+    ranges.push_back(ListRange{src_off[l], src_cnt[l]});
+    groups.back().nranges++;
+    groups.back().nsrc += src_cnt[l];
+    pairs += trg_cnt[l] * src_cnt[l];
+  }
+  for (const Group& g : groups)
+    if (g.nranges > INT32_MAX) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "too many lists for one target range");
+  // two targets per lane halve the LDS reads per pair (eval_kernel.hpp) but waste lanes on small boxes: from ~96 targets per box on
+  const int t_idx = (!groups.empty() && trg_in_groups / (int64_t)groups.size() >= 96) ? 1 : 0;
+  const int64_t per_item = (int64_t)kListWave * (t_idx ? 2 : 1);
+  std::vector<size_t> gorder(groups.size());
+  std::iota(gorder.begin(), gorder.end(), (size_t)0);
+  std::stable_sort(gorder.begin(), gorder.end(), [&](size_t a, size_t b) { return groups[a].nsrc > groups[b].nsrc; });   // long items first: short tail
+  std::vector<ListItem> items;
+  for (size_t gi : gorder) {
+    const Group& g = groups[gi];
+    for (int64_t t = 0; t < g.nt; t += per_item)
+      items.push_back(ListItem{g.t0 + t, (int32_t)std::min<int64_t>(per_item, g.nt - t), (int32_t)g.nranges, g.first_range});
+  }
+  if (items.size() > 0x7fffffffu) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "too many work items for one launch");
+
+  sctl_amd_lists* p = new sctl_amd_lists;
+  p->k = k; p->real = real; p->device = device; p->t_idx = t_idx; p->Nt = Nt; p->Ns = Ns;
+  p->nitems = (int64_t)items.size(); p->nranges = (int64_t)ranges.size(); p->pairs = pairs;
+  *out = p;
+  if (items.empty()) return SCTL_AMD_OK;       // nothing to do: legal, and needs no device
+  const int avail = device_count_quiet();
+  if (avail <= 0) { delete p; *out = nullptr; return set_error(SCTL_AMD_ERR_NO_DEVICE, "no HIP device: libsctl_amd has no CPU fallback"); }
+  if (device < 0 || device >= avail) { delete p; *out = nullptr; return set_error(SCTL_AMD_ERR_NO_DEVICE, "device index out of range"); }
+  DeviceScope scope(device);
+  auto fail_hip = [&](hipError_t e, const char* what) {
+    sctl_amd_lists_destroy(p);
+    *out = nullptr;
+    return set_error(SCTL_AMD_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+  };
+  if (scope.err != hipSuccess) return fail_hip(scope.err, "hipSetDevice");
+  hipError_t e;
+  if ((e = hipMalloc(&p->d_items, items.size() * sizeof(ListItem))) != hipSuccess) return fail_hip(e, "hipMalloc(items)");
+  if ((e = hipMalloc(&p->d_ranges, ranges.size() * sizeof(ListRange))) != hipSuccess) return fail_hip(e, "hipMalloc(ranges)");
+  // the vectors are fresh, written once and alive until the synchronous copies return
+  if ((e = hipMemcpy(p->d_items, items.data(), items.size() * sizeof(ListItem), hipMemcpyHostToDevice)) != hipSuccess) return fail_hip(e, "hipMemcpy(items)");
+  if ((e = hipMemcpy(p->d_ranges, ranges.data(), ranges.size() * sizeof(ListRange), hipMemcpyHostToDevice)) != hipSuccess) return fail_hip(e, "hipMemcpy(ranges)");
+  return SCTL_AMD_OK;
+}
+
+void sctl_amd_lists_destroy(sctl_amd_lists* p) {
+  if (!p) return;
+  if (p->d_items || p->d_ranges || p->st || p->pinned) {
+    DeviceScope scope(p->device);
+    if (scope.err == hipSuccess) {
+      if (p->st) (void)hipStreamSynchronize(p->st);
+      for (void* b : {p->d_items, p->d_ranges, p->dbuf[0], p->dbuf[1], p->dbuf[2], p->dbuf[3], p->dbuf[4]})
+        if (b) (void)hipFree(b);
+      if (p->pinned) (void)hipHostFree(p->pinned);
+      if (p->st) (void)hipStreamDestroy(p->st);
+    }
+  }
+  delete p;
+}
+
+int sctl_amd_lists_info(const sctl_amd_lists* p, int64_t* pairs, int64_t* work_items, int64_t* source_ranges, int* trg_per_lane) {
+  if (!p) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "null handle");
+  if (pairs) *pairs = p->pairs;
+  if (work_items) *work_items = p->nitems;
+  if (source_ranges) *source_ranges = p->nranges;
+  if (trg_per_lane) *trg_per_lane = p->t_idx ? 2 : 1;
+  return SCTL_AMD_OK;
+}
+
+int sctl_amd_lists_eval_device(sctl_amd_lists* p, const void* r_trg, const void* r_src, const void* n_src, const void* v_src, void* v_trg, int digits,
+                               const void* ctx, int ctx_bytes, void* stream) {
+  if (!p) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "null handle");
+  const KernelEntry& k = *p->k;
+  if (k.ctx_bytes != 0 && (ctx_bytes != k.ctx_bytes || !ctx))
+    return set_error(SCTL_AMD_ERR_BAD_CONTEXT, std::string(k.name) + " needs a context blob of " + std::to_string(k.ctx_bytes) + " bytes");
+  if (p->nitems == 0) return SCTL_AMD_OK;
+  if (!r_trg || !r_src || !v_src || !v_trg || (k.nd > 0 && !n_src)) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "null coordinate, normal, density or potential array");
+  (void)hipGetLastError();
+  const int mode = mode_for(p->real, digits);
+  const double scale = k.scale / k.acc_factor[mode];
+  if (p->real == SCTL_AMD_F64) {
+    ListArgs<double> a{(const ListItem*)p->d_items, (const ListRange*)p->d_ranges, (const double*)r_trg, (const double*)r_src, (const double*)n_src,
+                       (const double*)v_src, (double*)v_trg, scale, make_ctx(k, ctx)};
+    k.lists_f64[mode][p->t_idx](a, p->nitems, (hipStream_t)stream);
+  } else {
+    ListArgs<float> a{(const ListItem*)p->d_items, (const ListRange*)p->d_ranges, (const float*)r_trg, (const float*)r_src, (const float*)n_src,
+                      (const float*)v_src, (float*)v_trg, (float)scale, make_ctx(k, ctx)};
+    k.lists_f32[mode][p->t_idx](a, p->nitems, (hipStream_t)stream);
+  }
+  LISTS_TRY(hipGetLastError());
+  count_work(p->pairs, k);
+  return SCTL_AMD_OK;
+}
+
+int sctl_amd_lists_eval_host(sctl_amd_lists* p, const void* r_trg, const void* r_src, const void* n_src, const void* v_src, void* v_trg, int digits,
+                             const void* ctx, int ctx_bytes) {
+  if (!p) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "null handle");
+  const KernelEntry& k = *p->k;
+  if (k.ctx_bytes != 0 && (ctx_bytes != k.ctx_bytes || !ctx))
+    return set_error(SCTL_AMD_ERR_BAD_CONTEXT, std::string(k.name) + " needs a context blob of " + std::to_string(k.ctx_bytes) + " bytes");
+  if (p->nitems == 0) return SCTL_AMD_OK;
+  if (!r_trg || !r_src || !v_src || !v_trg || (k.nd > 0 && !n_src)) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "null coordinate, normal, density or potential array");
+  const size_t rs = (p->real == SCTL_AMD_F64) ? 8 : 4;
+  const size_t bytes[5] = {(size_t)p->Nt * 3 * rs, (size_t)p->Ns * 3 * rs, (size_t)p->Ns * k.nd * rs, (size_t)p->Ns * k.k0 * rs, (size_t)p->Nt * k.k1 * rs};
+  const void* src[4] = {r_trg, r_src, n_src, v_src};
+  DeviceScope scope(p->device);
+  LISTS_TRY(scope.err);
+  if (!p->st) LISTS_TRY(hipStreamCreateWithFlags(&p->st, hipStreamNonBlocking));
+  size_t total = 0;
+  for (int i = 0; i < 5; i++) {
+    total += Carver::pad(bytes[i]);
+    if (bytes[i] > p->dcap[i]) {
+      if (p->dbuf[i]) { LISTS_TRY(hipFree(p->dbuf[i])); p->dbuf[i] = nullptr; p->dcap[i] = 0; }
+      LISTS_TRY(hipMalloc(&p->dbuf[i], bytes[i]));
+      p->dcap[i] = bytes[i];
+    }
+  }
+  if (total > p->pinned_cap) {   // every host transfer goes through pinned staging (capi.hip: PinnedBuf explains why)
+    if (p->pinned) { LISTS_TRY(hipHostFree(p->pinned)); p->pinned = nullptr; p->pinned_cap = 0; }
+    LISTS_TRY(hipHostMalloc((void**)&p->pinned, total, hipHostMallocPortable));
+    p->pinned_cap = total;
+  }
+  Carver cut(p->pinned);
+  for (int i = 0; i < 4; i++) {
+    char* q = cut.take<char>(bytes[i]);
+    if (!bytes[i]) continue;
+    std::memcpy(q, src[i], bytes[i]);
+    LISTS_TRY(hipMemcpyAsync(p->dbuf[i], q, bytes[i], hipMemcpyHostToDevice, p->st));
+  }
+  LISTS_TRY(hipMemsetAsync(p->dbuf[4], 0, bytes[4], p->st));
+  const int rc = sctl_amd_lists_eval_device(p, p->dbuf[0], p->dbuf[1], p->dbuf[2], p->dbuf[3], p->dbuf[4], digits, ctx, ctx_bytes, p->st);
+  if (rc != SCTL_AMD_OK) return rc;
+  char* back = cut.take<char>(bytes[4]);
+  LISTS_TRY(hipMemcpyAsync(back, p->dbuf[4], bytes[4], hipMemcpyDeviceToHost, p->st));
+  LISTS_TRY(hipStreamSynchronize(p->st));
+  const int64_t n = p->Nt * k.k1;      // v_trg += device result (accumulate semantics of GenericKernel::Eval)
+  if (p->real == SCTL_AMD_F64) { double* o = (double*)v_trg; const double* s = (const double*)back; for (int64_t i = 0; i < n; i++) o[i] += s[i]; }
+  else { float* o = (float*)v_trg; const float* s = (const float*)back; for (int64_t i = 0; i < n; i++) o[i] += s[i]; }
+  return SCTL_AMD_OK;
+}
+
+// one-shot forms: plan, evaluate, release
+int sctl_amd_eval_lists_device(int kernel, int real, int64_t nlists, const int64_t* trg_off, const int64_t* trg_cnt, const int64_t* src_off,
+                               const int64_t* src_cnt, int64_t Nt, int64_t Ns, const void* r_trg, const void* r_src, const void* n_src, const void* v_src,
+                               void* v_trg, int digits, const void* ctx, int ctx_bytes, void* stream) {
+  int dev = 0;
+  if (device_count_quiet() > 0 && hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+  sctl_amd_lists* p = nullptr;
+  int rc = sctl_amd_lists_create(kernel, real, dev, nlists, trg_off, trg_cnt, src_off, src_cnt, Nt, Ns, &p);
+  if (rc != SCTL_AMD_OK) return rc;
+  rc = sctl_amd_lists_eval_device(p, r_trg, r_src, n_src, v_src, v_trg, digits, ctx, ctx_bytes, stream);
+  if (rc == SCTL_AMD_OK && p->nitems > 0 && hipStreamSynchronize((hipStream_t)stream) != hipSuccess)   // the work list is freed below
+    rc = set_error(SCTL_AMD_ERR_HIP, "hipStreamSynchronize failed after the list evaluation");
+  sctl_amd_lists_destroy(p);
+  return rc;
+}
+
+int sctl_amd_eval_lists_host(int kernel, int real, int64_t nlists, const int64_t* trg_off, const int64_t* trg_cnt, const int64_t* src_off,
+                             const int64_t* src_cnt, int64_t Nt, int64_t Ns, const void* r_trg, const void* r_src, const void* n_src, const void* v_src,
+                             void* v_trg, int digits, const void* ctx, int ctx_bytes, int device) {
+  sctl_amd_lists* p = nullptr;
+  int rc = sctl_amd_lists_create(kernel, real, device, nlists, trg_off, trg_cnt, src_off, src_cnt, Nt, Ns, &p);
+  if (rc != SCTL_AMD_OK) return rc;
+  rc = sctl_amd_lists_eval_host(p, r_trg, r_src, n_src, v_src, v_trg, digits, ctx, ctx_bytes);
+  sctl_amd_lists_destroy(p);
+  return rc;
+}
+
+}  // extern "C"

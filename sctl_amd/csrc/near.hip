@@ -2,7 +2,7 @@
 // operator matrices stay resident in HBM; one application is a batch of small row-major GEMVs U_ = F_ . K_near_
 // (boundary_integral.txx:1092-1102), the permutation by near_scatter_index (:1129) and the per-target accumulation
 // (:1131-1140).  HBM-bound: every byte of K_near is read exactly once per application and nothing else is of that order.
-#include "../../include/sctl_amd.h"
+#include <sctl_amd.h>
 #include "workspace.hpp"
 
 #include <hip/hip_runtime.h>

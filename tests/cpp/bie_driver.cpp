@@ -234,7 +234,13 @@ template <class Kernel> int run(long seed, Long Nt, Long Ns, Long npe, Long ups,
     Vector<Real> Un, U3 = U2;
     op.ComputeNearInterac(Un, f);
     op.ComputeNearInterac(U3, f);                                   // a right-sized vector is accumulated into
-    for (Long i = 0; i < U.Dim(); i++) SCTL_AMD_ASSERT(U[i] == U3[i]);
+    // the two legs one after the other == the fused ComputePotential, up to the order in which far field and near entries are added
+    Real dmax = 0, umax = 0;
+    for (Long i = 0; i < U.Dim(); i++) { dmax = std::max(dmax, std::fabs(U[i] - U3[i])); umax = std::max(umax, std::fabs(U[i])); }
+    SCTL_AMD_ASSERT(dmax <= 1e-14 * umax);
+    Vector<Real> U4;
+    op.ComputePotential(U4, f);                                     // and evaluating again gives the same bits
+    for (Long i = 0; i < U.Dim(); i++) SCTL_AMD_ASSERT(U[i] == U4[i]);
     Un.Write((std::string(out) + ".near").c_str());
   } else {
     for (Long i = 0; i < U.Dim(); i++) SCTL_AMD_ASSERT(U[i] == U2[i]);   // no near zone: ComputePotential == ComputeFarField

@@ -1,6 +1,6 @@
 // CPU check of sctl_amd/csrc/fastmath.hpp (the fp64 sincos / exp used by the Helmholtz device kernel) against libm in
 // long double.  Prints the maximum errors; tests/test_fastmath.py asserts the bounds.  Built with g++ (no HIP needed).
-#include "../../sctl_amd/csrc/fastmath.hpp"
+#include "../../include/sctl_amd/device/fastmath.hpp"
 
 #include <cmath>
 #include <cstdio>

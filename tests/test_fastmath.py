@@ -1,4 +1,4 @@
-"""CPU check of the fp64 sincos / exp the Helmholtz device kernel uses (sctl_amd/csrc/fastmath.hpp is host+device code)."""
+"""CPU check of the fp64 sincos / exp the Helmholtz device kernel uses (include/sctl_amd/device/fastmath.hpp is host+device code)."""
 import os
 import re
 import subprocess

@@ -187,3 +187,42 @@ def test_boundary_integral_near_field_end_to_end(tmp_path, case):
     u, un = _read_vector(out), _read_vector(out + ".near")
     assert rel_l2(un, gold(case, "u_near")) < 1e-12, rel_l2(un, gold(case, "u_near"))
     assert rel_l2(u, gold(case, "u_total")) < 1e-10, rel_l2(u, gold(case, "u_total"))     # the reference's far field ran at tol 1e-10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devs", [(0,), (0, 0), (0, 0, 0)], ids=["1dev", "2slabs", "3slabs"])
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_fused_compute_potential_on_the_operator_handle(O, case, devs):
+    """sctl_amd_op_set_near + sctl_amd_op_eval_potential: far field and near field of one BoundaryIntegralOp in one pass over the devices,
+    the near operator block-partitioned by target slab (one GPU listed two or three times stands in for a multi-GPU node).  Fed with the
+    REFERENCE's near-operator arrays; expected = the reference's ComputePotential (minus a matrix-free list's share, which is host work)."""
+    k0, k1 = dims(O, case)
+    xt, xnt, xs, xn, w, f = near_inputs(case, k0)
+    arrs = {k: gold(case, k) for k in ("elem_nds_cnt", "near_elem_cnt", "K_near_cnt", "K_near", "near_scatter_index", "near_trg_cnt", "near_trg_dsp")}
+    self_trg = case["Nt"] == 0
+    T, Tn = (xs, xn) if self_trg else (xt, xnt)
+    ups = case["upsample"]
+    info = O.info(case["kernel"])
+    # the far-field quadrature of PatchElemList: every node repeated `ups` times with weight w / ups, density copied to the copies
+    x_far, n_far = np.repeat(xs.reshape(-1, 3), ups, 0).ravel(), np.repeat(xn.reshape(-1, 3), ups, 0).ravel()
+    w_far, f_far = np.repeat(w / ups, ups), np.repeat(f.reshape(-1, k0), ups, 0).ravel()
+    op = sctl_amd.DirectOp(case["kernel"], np.float64, devices=devs)
+    op.set_targets(T)
+    op.set_sources(x_far, n_far if info["nd"] else None)
+    op.set_source_weights(w_far)
+    if case["trg_normal_dot_prod"]:
+        op.set_target_normals(Tn)
+    op.set_near(k1, arrs["elem_nds_cnt"], arrs["near_elem_cnt"], arrs["K_near"], arrs["near_scatter_index"], arrs["near_trg_cnt"], arrs["near_trg_dsp"],
+                K_near_cnt=arrs["K_near_cnt"])
+    expect = gold(case, "u_total") - matrix_free_part(O, case, arrs, xt, xnt, xs, xn, w, f)
+    u = op.eval_potential(f_far, f, digits=11)
+    assert rel_l2(u, expect) < 1e-10, rel_l2(u, expect)                    # the reference's far field ran at tol 1e-10
+    far = op.eval(f_far, digits=11)                                        # the two legs separately agree to rounding
+    near = sctl_amd.NearOp(k0, k1, **arrs).apply(f)
+    assert rel_l2(u, far + near) < 1e-14
+    u2 = op.eval_potential(f_far, f, v_trg=u.copy(), accumulate=True, digits=11)
+    assert rel_l2(u2, 2 * u) < 1e-15
+    op.set_targets(T)                                                      # new targets drop the attached operator
+    with pytest.raises(sctl_amd.api.SctlAmdError, match="no near-field operator"):
+        op.eval_potential(f_far, f)
+    op.close()
