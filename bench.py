@@ -72,12 +72,19 @@ def cpu_baseline(kernel, N, dtype, budget_s=12.0):
 
 
 def read_traffic(workload):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/hbm_traffic.json), or None."""
-    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    """HBM bytes per launch of the workload's dominant kernel, from the committed rocprofv3 --pmc passes (profiles/hbm_traffic.json; counters
+    cannot be read from inside this process).  None — never a stale number — unless the kernel the record names still exists in the
+    library that is being measured (its name tokens must appear among the code object's symbols)."""
     try:
-        with open(path) as fh:
-            return json.load(fh).get(workload, {}).get("hbm_bytes_per_launch")
-    except (OSError, ValueError):
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as fh:
+            rec = json.load(fh).get(workload)
+        if not rec or not rec.get("symbol_tokens"):
+            return None
+        import sctl_amd
+        with open(sctl_amd.library_path(), "rb") as fh:
+            blob = fh.read()
+        return rec["hbm_bytes_per_launch"] if all(t.encode() in blob for t in rec["symbol_tokens"]) else None
+    except (OSError, ValueError, KeyError):
         return None
 
 
@@ -189,7 +196,7 @@ def bench_lists(args):
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "batched list evaluation: %d (target box x source box) lists, 2^21 uniform points in 16^3 boxes (%d..%d per box), targets == sources, %s"
                                    % (lists[0].size, counts.min(), counts.max(), kernel), "kernel": kernel, "lists": int(lists[0].size), "pairs_per_step": plan.pairs,
-                       "work_items": plan.work_items, "trg_per_lane": plan.trg_per_lane, "digits": args.digits},
+                       "work_items": plan.work_items, "digits": args.digits},
             "roofline": {"bound": "mfma", "pipe": "fp64 VALU", "achieved": achieved, "peak": PEAK_TFLOPS["f64"], "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS["f64"],
                          "traffic": read_traffic("p2p_lists"), "flops_per_pair": fpp, "kernel_ms": k_ms,
                          "note": "vector-FMA bound: algorithmic flops = listed pairs x (3 + FLOPS() + 2 K0 K1); one launch per step"}}
@@ -197,7 +204,7 @@ def bench_lists(args):
         from concurrent.futures import ThreadPoolExecutor
         R = cpu_impl()
         nthreads = min(os.cpu_count() or 1, 32)
-        nb_sample = 512                                            # target boxes of the sample (all their lists)
+        nb_sample = grid ** 3                                      # target boxes of the sample: all of them (a few seconds of CPU work)
         to, tc, so, sc = lists
         sel = np.flatnonzero(np.isin(to, np.unique(to)[:nb_sample]))
         uh = np.zeros(N)

@@ -86,7 +86,7 @@ int sctl_amd_num_kernels(void);                 /* built-in + registered: valid 
  * make_entry<Ker>() builds (function pointers into the plugin's own code object); abi_version and desc_bytes guard against a
  * plugin compiled with other device headers.  Returns the new kernel id (>= SCTL_AMD_NUM_KERNELS) or a negative error code
  * (a name that is already registered is refused).  Registered kernels live until the process ends. */
-#define SCTL_AMD_DEVICE_ABI 2
+#define SCTL_AMD_DEVICE_ABI 3
 typedef struct sctl_amd_kernel_desc {
   int abi_version;          /* SCTL_AMD_DEVICE_ABI of the headers the plugin was compiled with */
   int desc_bytes;           /* sizeof(sctl_amd_kernel_desc) */
@@ -176,6 +176,33 @@ int sctl_amd_op_set_target_normals(sctl_amd_op* op, const void* n_trg);
 int sctl_amd_op_eval(sctl_amd_op* op, const void* v_src, void* v_trg, int accumulate, int digits, const void* ctx, int ctx_bytes);
 void sctl_amd_op_destroy(sctl_amd_op* op);
 
+/* ---- rank-parallel evaluation: one process per GPU (ParticleFMM::EvalDirect under MPI, fmm-wrapper.txx:504-561) --------------- */
+/* The reference partitions targets and sources over MPI ranks and rotates the source blocks round a ring (:537-558).  Here every
+ * rank keeps ITS targets, and the sources (and, per evaluation, the densities) of ALL ranks are all-gathered into each rank's
+ * device-resident operator: over RCCL / xGMI, GPU buffer to GPU buffer, when every rank drives its own GPU.  There is no MPI
+ * behind this: ranks meet through a TCP rendezvous (rank 0 listens on master_addr:master_port; dotted IPv4), which carries the
+ * RCCL unique id, the small host-side collectives below, and — when ranks SHARE a GPU, which RCCL refuses: a one-GPU rehearsal —
+ * the data itself.  create() is collective (every rank calls it; blocks until all have connected).  device: the HIP device of
+ * this rank, or -1 for a host-only communicator (the host collectives work without any GPU).  flags: SCTL_AMD_COMM_SOCKETS_ONLY
+ * keeps RCCL out even when it could be used. */
+typedef struct sctl_amd_comm sctl_amd_comm;
+enum { SCTL_AMD_COMM_SOCKETS_ONLY = 1 };
+enum { SCTL_AMD_COMM_SOCKETS = 0, SCTL_AMD_COMM_RCCL = 1 };   /* sctl_amd_comm_info: transport of the data path */
+int sctl_amd_comm_create(int rank, int size, const char* master_addr, int master_port, int device, int flags, sctl_amd_comm** comm);
+int sctl_amd_comm_info(const sctl_amd_comm* comm, int* rank, int* size, int* device, int* transport);
+/* Host-side collectives over the rendezvous sockets (counts, small arrays): every rank contributes send_bytes bytes, recv gets
+ * the concatenation in rank order (at most recv_capacity bytes) and bytes_of_rank[size] the contributions. */
+int sctl_amd_comm_allgatherv_host(sctl_amd_comm* comm, const void* send, int64_t send_bytes, void* recv, int64_t recv_capacity, int64_t* bytes_of_rank);
+int sctl_amd_comm_barrier(sctl_amd_comm* comm);
+void sctl_amd_comm_destroy(sctl_amd_comm* comm);
+/* Collective forms of sctl_amd_op_set_sources / sctl_amd_op_eval for an operator with ONE device (this rank's): the operator's
+ * sources become the concatenation, in rank order, of all ranks' Ns_local sources (HOST arrays); eval_dist gathers the ranks'
+ * densities the same way and evaluates THIS rank's targets (set with sctl_amd_op_set_targets), v_trg holding their Nt*TrgDim
+ * values.  Every rank must call them, in the same order; a rank may own no sources or no targets. */
+int sctl_amd_op_set_sources_dist(sctl_amd_op* op, sctl_amd_comm* comm, int64_t Ns_local, const void* r_src, const void* n_src);
+int sctl_amd_op_eval_dist(sctl_amd_op* op, sctl_amd_comm* comm, int64_t Ns_local, const void* v_src_local, void* v_trg, int accumulate, int digits,
+                          const void* ctx, int ctx_bytes);
+
 /* ---- BoundaryIntegralOp near field: ComputeNearInterac (boundary_integral.txx:1079-1142) -------------------------- */
 /* The step that follows the far field in ComputePotential (:608-614): for every element the precomputed operator block
  * K_near_ ((elem_nds_cnt[e]*src_dim) x (near_elem_cnt[e]*trg_dim), row-major) is applied to the element's density,
@@ -237,8 +264,8 @@ int sctl_amd_lists_eval_device(sctl_amd_lists* plan, const void* r_trg, const vo
                                int digits, const void* ctx, int ctx_bytes, void* stream);
 int sctl_amd_lists_eval_host(sctl_amd_lists* plan, const void* r_trg, const void* r_src, const void* n_src, const void* v_src, void* v_trg,
                              int digits, const void* ctx, int ctx_bytes);
-/* pair interactions of one evaluation, work items (waves) and source ranges of the launch, targets per lane.  NULL = skip. */
-int sctl_amd_lists_info(const sctl_amd_lists* plan, int64_t* pairs, int64_t* work_items, int64_t* source_ranges, int* trg_per_lane);
+/* pair interactions of one evaluation, work items (waves) and source ranges of the launch.  NULL = skip. */
+int sctl_amd_lists_info(const sctl_amd_lists* plan, int64_t* pairs, int64_t* work_items, int64_t* source_ranges);
 void sctl_amd_lists_destroy(sctl_amd_lists* plan);
 /* One-shot forms (plan, evaluate, release).  _device: arrays on the current device; returns after the stream has finished. */
 int sctl_amd_eval_lists_device(int kernel, int real, int64_t nlists, const int64_t* trg_off, const int64_t* trg_cnt, const int64_t* src_off,
@@ -255,6 +282,12 @@ void sctl_amd_reset_counters(void);
 /* Frees the device scratch memory the library keeps per (device, stream) between calls (partial sums, the sort buffers
  * of the tile-centred path: up to ~0.3 GB per stream at 2^20 points).  Waits for the devices.  Optional. */
 void sctl_amd_trim(void);
+
+/* Debugging switches (a bit mask; returns the previous mask).  SCTL_AMD_DEBUG_POISON_SCRATCH: every evaluation first fills the
+ * device scratch it is about to use (partial sums, sort buffers) with NaN bit patterns, so that a read of scratch the call did not
+ * write shows up as NaN in the result instead of as the previous call's numbers.  Costs one memset per call; off by default. */
+#define SCTL_AMD_DEBUG_POISON_SCRATCH 1
+int sctl_amd_set_debug(int flags);
 
 /* Launch geometry chosen for a problem (for benchmarks and DESIGN.md; no side effects):
  * targets per lane, source splits, workgroups, and bytes of the partial-sum workspace.

@@ -26,8 +26,8 @@ struct KernelEntry {
   MatrixLaunch<float> matrix_f32[kNumMode];
   MatrixBatchLaunch<double> matrix_batch_f64[kNumMode];
   MatrixBatchLaunch<float> matrix_batch_f32[kNumMode];
-  ListsLaunch<double> lists_f64[kNumMode][2];       // [mode][targets per lane: 1, 2]  (lists_kernel.hpp)
-  ListsLaunch<float> lists_f32[kNumMode][2];
+  ListsLaunch<double> lists_f64[kNumMode];          // lists_kernel.hpp
+  ListsLaunch<float> lists_f32[kNumMode];
 };
 
 template <class Ker, class R, int MODE, int T> void launch_eval(const EvalArgs<R>& a, dim3 grid, hipStream_t st) {
@@ -43,8 +43,8 @@ template <class Ker, class R, int MODE> void launch_matrix_batch(const MatTile* 
   hipLaunchKernelGGL((matrix_batch_kernel<Ker, R, MODE>), dim3((unsigned)ntiles), dim3(kBlock), 0, st, tiles, xt, xs, xn, M, scale, ctx);
 }
 
-template <class Ker, class R, int MODE, int T> void launch_lists(const ListArgs<R>& a, int64_t nitems, hipStream_t st) {
-  hipLaunchKernelGGL((lists_kernel<Ker, R, MODE, T>), dim3((unsigned)nitems), dim3(kListWave), 0, st, a);
+template <class Ker, class R, int MODE> void launch_lists(const ListArgs<R>& a, int64_t nitems, hipStream_t st) {
+  hipLaunchKernelGGL((lists_kernel<Ker, R, MODE>), dim3((unsigned)nitems), dim3(kListWave), 0, st, a);
 }
 
 template <class Ker> KernelEntry make_entry(int ctx_bytes) {
@@ -63,10 +63,8 @@ template <class Ker> KernelEntry make_entry(int ctx_bytes) {
   e.matrix_batch_f64[2] = launch_matrix_batch<Ker, double, 2>;
   e.matrix_batch_f32[0] = launch_matrix_batch<Ker, float, 0>; e.matrix_batch_f32[1] = launch_matrix_batch<Ker, float, 1>;
   e.matrix_batch_f32[2] = launch_matrix_batch<Ker, float, 1>;
-#define SCTL_AMD_LROW(R, arr, M, MM) arr[M][0] = launch_lists<Ker, R, MM, 1>; arr[M][1] = launch_lists<Ker, R, MM, 2>;
-  SCTL_AMD_LROW(double, e.lists_f64, 0, 0) SCTL_AMD_LROW(double, e.lists_f64, 1, 1) SCTL_AMD_LROW(double, e.lists_f64, 2, 2)
-  SCTL_AMD_LROW(float, e.lists_f32, 0, 0) SCTL_AMD_LROW(float, e.lists_f32, 1, 1) SCTL_AMD_LROW(float, e.lists_f32, 2, 1)
-#undef SCTL_AMD_LROW
+  e.lists_f64[0] = launch_lists<Ker, double, 0>; e.lists_f64[1] = launch_lists<Ker, double, 1>; e.lists_f64[2] = launch_lists<Ker, double, 2>;
+  e.lists_f32[0] = launch_lists<Ker, float, 0>; e.lists_f32[1] = launch_lists<Ker, float, 1>; e.lists_f32[2] = launch_lists<Ker, float, 1>;
   return e;
 }
 

@@ -11,7 +11,8 @@
 //   * the item's source ranges are streamed as ONE concatenated sequence through a 64-record LDS tile (a tile may span several
 //     small ranges: 27 neighbour boxes of 5 points fill three tiles, not 27); the next tile's sources are fetched into registers
 //     while the current tile is evaluated;
-//   * the pair evaluation is the kernel's own exact, masked pair() (a box interacts with itself: coincident points are the norm).
+//   * the pair evaluation is the kernel's own exact pair(); a box interacts with itself, so tiles are evaluated speculatively
+//     without the r = 0 mask and repaired when a coincident pair shows up (as in eval_kernel.hpp).
 #pragma once
 #include "eval_kernel.hpp"
 
@@ -22,7 +23,7 @@ constexpr int kListTile = 64;    // sources per LDS tile
 
 struct ListItem {       // one wave
   int64_t t0;           // first target (point index)
-  int32_t nt;           // targets of this item, 1 .. 64*T
+  int32_t nt;           // targets of this item: 65 .. 128 (two per lane) or 1 .. 64 (one per lane)
   int32_t nranges;      // source ranges of the target box
   int64_t first_range;  // index of the first one in the range array
 };
@@ -43,20 +44,16 @@ template <class R> struct ListArgs {
   KerCtx ctx;
 };
 
-template <class Ker, class R, int MODE, int T>
-__global__ void __launch_bounds__(kListWave) lists_kernel(const ListArgs<R> a) {
+// One work item with T targets per lane.  Each LDS tile is first evaluated WITHOUT the r = 0 mask into per-tile sums; a coincident
+// pair (a box acting on itself: 1 of its ~27 lists) poisons them with inf/NaN, which one compare per tile detects, and the wave
+// re-runs that tile masked — the same speculation as eval_kernel.hpp, worth ~9 % on the Laplace kernel.
+template <class Ker, class R, int MODE, int T, class KC, class V>
+__device__ __forceinline__ void lists_item(const ListArgs<R>& a, const ListItem& it, V* tile, const KC& K) {
   constexpr int K0 = Ker::K0, K1 = Ker::K1, ND = Ker::ND, NREC = Ker::NREC;
-  using V = typename VecOf<R>::type;
   constexpr int VN = VecOf<R>::N;
   constexpr int NV = (NREC + VN - 1) / VN;
   constexpr int NRECP = NV * VN;
-  __shared__ V tile[kListTile * NV];
-  using KC = typename Ker::template Consts<R>;
-  __shared__ double kscratch[KC::LDS_DOUBLES > 0 ? KC::LDS_DOUBLES : 1];
-  const KC K(kscratch);
-
   const int lane = threadIdx.x;
-  const ListItem it = a.items[blockIdx.x];
   const ListRange* const rg = a.ranges + it.first_range;
 
   R xt[T][3], acc[T][K1];
@@ -100,6 +97,8 @@ __global__ void __launch_bounds__(kListWave) lists_kernel(const ListArgs<R> a) {
     return fill;
   };
 
+  int repairs = 0, tiles = 0;
+  bool always_masked = false;
   int ns = fetch();
   while (ns > 0) {
     __syncthreads();   // previous tile fully consumed
@@ -118,8 +117,15 @@ __global__ void __launch_bounds__(kListWave) lists_kernel(const ListArgs<R> a) {
     ns = fetch();      // loads for the next tile are in flight during this tile's arithmetic
     __syncthreads();
 
-    auto run_tile = [&](auto variant_tag) {
+    R tacc[T][K1];
+    auto run_tile_v = [&](auto masked_tag, auto variant_tag) {
+      constexpr bool MASKED = decltype(masked_tag)::value;
       constexpr bool VARIANT = decltype(variant_tag)::value;
+      K.begin_tile();
+#pragma unroll
+      for (int j = 0; j < T; j++)
+#pragma unroll
+        for (int k = 0; k < K1; k++) tacc[j][k] = 0;
       auto one_source = [&](int s) {
         R rec[NRECP];
 #pragma unroll
@@ -131,8 +137,8 @@ __global__ void __launch_bounds__(kListWave) lists_kernel(const ListArgs<R> a) {
 #pragma unroll
         for (int j = 0; j < T; j++) {
           const R d[3] = {xt[j][0] - rec[0], xt[j][1] - rec[1], xt[j][2] - rec[2]};
-          if constexpr (KC::HAS_VARIANT) Ker::template pair<R, MODE, true, VARIANT>(acc[j], d, rec, a.ctx, K);
-          else Ker::template pair<R, MODE, true>(acc[j], d, rec, a.ctx, K);
+          if constexpr (KC::HAS_VARIANT) Ker::template pair<R, MODE, MASKED, VARIANT>(tacc[j], d, rec, a.ctx, K);
+          else Ker::template pair<R, MODE, MASKED>(tacc[j], d, rec, a.ctx, K);
         }
       };
       if (ns_cur == kListTile) {
@@ -142,12 +148,31 @@ __global__ void __launch_bounds__(kListWave) lists_kernel(const ListArgs<R> a) {
         for (int s = 0; s < ns_cur; s++) one_source(s);
       }
     };
-    if constexpr (KC::HAS_VARIANT) {   // a launch-uniform special case of the kernel (Helmholtz: real wavenumber) has its own loop
-      if (K.variant(a.ctx)) run_tile(std::true_type());
-      else run_tile(std::false_type());
-    } else {
+    auto run_tile = [&](auto masked_tag) {   // a launch-uniform special case of the kernel (Helmholtz: real wavenumber) has its own loop
+      if constexpr (KC::HAS_VARIANT) {
+        if (K.variant(a.ctx)) run_tile_v(masked_tag, std::true_type());
+        else run_tile_v(masked_tag, std::false_type());
+      } else {
+        run_tile_v(masked_tag, std::false_type());
+      }
+    };
+    bool repaired = true;
+    tiles++;
+    if (!always_masked) {
       run_tile(std::false_type());
+      bool bad = K.tile_bad(a.ctx);
+#pragma unroll
+      for (int j = 0; j < T; j++)
+#pragma unroll
+        for (int k = 0; k < K1; k++) bad |= !(fabs_(tacc[j][k]) <= max_finite<R>());
+      repaired = __any(bad);                 // wave-uniform
+      if (repaired && (++repairs) * 4 > tiles + 4) always_masked = true;   // mostly coincident points (tiny boxes): stop speculating
     }
+    if (repaired) run_tile(std::true_type());
+#pragma unroll
+    for (int j = 0; j < T; j++)
+#pragma unroll
+      for (int k = 0; k < K1; k++) acc[j][k] += tacc[j][k];
   }
 
 #pragma unroll
@@ -159,6 +184,21 @@ __global__ void __launch_bounds__(kListWave) lists_kernel(const ListArgs<R> a) {
       for (int k = 0; k < K1; k++) a.v_trg[t * K1 + k] += acc[j][k] * a.scale;   // generic-kernel.txx:184
     }
   }
+}
+
+// An item with more than 64 targets runs two targets per lane (half the LDS reads per pair), a smaller one a single target per lane
+// (no idle second slot): the host cuts every target range into 128-target items plus, for a remainder of at most 64, one such item.
+template <class Ker, class R, int MODE>
+__global__ void __launch_bounds__(kListWave) lists_kernel(const ListArgs<R> a) {
+  using V = typename VecOf<R>::type;
+  constexpr int NV = (Ker::NREC + VecOf<R>::N - 1) / VecOf<R>::N;
+  __shared__ V tile[kListTile * NV];
+  using KC = typename Ker::template Consts<R>;
+  __shared__ double kscratch[KC::LDS_DOUBLES > 0 ? KC::LDS_DOUBLES : 1];
+  const KC K(kscratch);
+  const ListItem it = a.items[blockIdx.x];
+  if (it.nt > kListWave) lists_item<Ker, R, MODE, 2>(a, it, tile, K);
+  else lists_item<Ker, R, MODE, 1>(a, it, tile, K);
 }
 
 }  // namespace sctl_amd

@@ -132,7 +132,11 @@ template <class Real, Integer DIM = 3> class ParticleFMM {
     SCTL_AMD_ASSERT(Xt.Dim() == Nt * DIM);
     if (U.Dim() != Nt * TrgDim) U.ReInit(Nt * TrgDim);
     U.SetZero();
-    const std::vector<int>& devs = DeviceSet::Get();
+    // Rank-parallel run (one process per GPU): this rank's targets stay, the sources and densities of ALL ranks are all-gathered into
+    // the operator on this rank's GPU (RCCL over xGMI) — the reference's contract of fmm-wrapper.txx:504-561 without its ring.
+    const bool ranks = comm_.Size() > 1;
+    const std::vector<int> rank_dev(1, comm_.Device());
+    const std::vector<int>& devs = ranks ? rank_dev : DeviceSet::Get();
     for (const auto& it : s2t_map_) {
       if (it.first.second != trg_name) continue;
       const std::string& src_name = it.first.first;
@@ -156,6 +160,14 @@ template <class Real, Integer DIM = 3> class ParticleFMM {
       if (s2t.trg_dirty) {
         CheckStatus(sctl_amd_op_set_targets(s2t.op, Nt, Xt.begin()), "sctl_amd_op_set_targets");
         s2t.trg_dirty = false;
+      }
+      if (ranks) {   // collective: every rank comes through here for every S2T pair, in map order; coordinates are re-gathered on
+                     // every evaluation (a rank cannot know whether ANOTHER rank moved its sources)
+        CheckStatus(sctl_amd_op_set_sources_dist(s2t.op, comm_.Handle(), Ns, src_data.X.begin(), NorDim ? src_data.Xn.begin() : nullptr), "sctl_amd_op_set_sources_dist");
+        s2t.src_dirty = true;
+        const int rc = sctl_amd_op_eval_dist(s2t.op, comm_.Handle(), Ns, src_data.F.begin(), U.begin(), 1, (int)digits_, s2t.ctx_bytes ? s2t.ctx.data() : nullptr, s2t.ctx_bytes);
+        CheckStatus(rc, "sctl_amd_op_eval_dist");
+        continue;
       }
       if (s2t.src_dirty) {
         CheckStatus(sctl_amd_op_set_sources(s2t.op, Ns, src_data.X.begin(), NorDim ? src_data.Xn.begin() : nullptr), "sctl_amd_op_set_sources");

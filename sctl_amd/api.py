@@ -26,7 +26,8 @@ SYMBOLS = ["sctl_amd_version", "sctl_amd_last_error", "sctl_amd_device_count", "
            "sctl_amd_eval_plan", "sctl_amd_eval_path", "sctl_amd_op_create", "sctl_amd_op_set_targets",
            "sctl_amd_op_set_sources", "sctl_amd_op_set_source_weights", "sctl_amd_op_set_target_normals", "sctl_amd_op_eval", "sctl_amd_op_destroy", "sctl_amd_near_create", "sctl_amd_near_apply_host",
            "sctl_amd_near_apply_device", "sctl_amd_near_info", "sctl_amd_near_destroy", "sctl_amd_num_kernels", "sctl_amd_register_kernel", "sctl_amd_load_plugin",
-           "sctl_amd_op_set_near", "sctl_amd_op_eval_potential", "sctl_amd_lists_create", "sctl_amd_lists_eval_device", "sctl_amd_lists_eval_host", "sctl_amd_lists_info", "sctl_amd_lists_destroy",
+           "sctl_amd_set_debug", "sctl_amd_comm_create", "sctl_amd_comm_info", "sctl_amd_comm_allgatherv_host", "sctl_amd_comm_barrier", "sctl_amd_comm_destroy",
+           "sctl_amd_op_set_sources_dist", "sctl_amd_op_eval_dist", "sctl_amd_op_set_near", "sctl_amd_op_eval_potential", "sctl_amd_lists_create", "sctl_amd_lists_eval_device", "sctl_amd_lists_eval_host", "sctl_amd_lists_info", "sctl_amd_lists_destroy",
            "sctl_amd_eval_lists_device", "sctl_amd_eval_lists_host"]
 
 
@@ -109,7 +110,7 @@ def lib():
     L.sctl_amd_lists_create.argtypes = [ci, ci, ci, i64, vp, vp, vp, vp, i64, i64, C.POINTER(vp)]
     L.sctl_amd_lists_eval_device.argtypes = [vp, vp, vp, vp, vp, vp, ci, vp, ci, vp]
     L.sctl_amd_lists_eval_host.argtypes = [vp, vp, vp, vp, vp, vp, ci, vp, ci]
-    L.sctl_amd_lists_info.argtypes = [vp, pi64, pi64, pi64, C.POINTER(ci)]
+    L.sctl_amd_lists_info.argtypes = [vp, pi64, pi64, pi64]
     L.sctl_amd_lists_destroy.argtypes = [vp]
     L.sctl_amd_lists_destroy.restype = None
     L.sctl_amd_eval_lists_host.argtypes = [ci, ci, i64, vp, vp, vp, vp, i64, i64, vp, vp, vp, vp, vp, ci, vp, ci, ci]
@@ -503,9 +504,8 @@ class ListsPlan:
         _check(lib().sctl_amd_lists_create(self.info["id"], self.real, device, arrs[0].size, p(arrs[0]), p(arrs[1]), p(arrs[2]), p(arrs[3]), self.Nt, self.Ns,
                                            C.byref(self._h)), "lists_create")
         v = [C.c_int64() for _ in range(3)]
-        t = C.c_int()
-        _check(lib().sctl_amd_lists_info(self._h, C.byref(v[0]), C.byref(v[1]), C.byref(v[2]), C.byref(t)), "lists_info")
-        self.pairs, self.work_items, self.source_ranges, self.trg_per_lane = v[0].value, v[1].value, v[2].value, t.value
+        _check(lib().sctl_amd_lists_info(self._h, C.byref(v[0]), C.byref(v[1]), C.byref(v[2])), "lists_info")
+        self.pairs, self.work_items, self.source_ranges = v[0].value, v[1].value, v[2].value
 
     def eval_host(self, r_trg, r_src, n_src, v_src, v_trg=None, digits=-1):
         """numpy arrays; v_trg of the right size is accumulated into, otherwise a fresh zeroed result is returned."""

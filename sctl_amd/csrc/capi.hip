@@ -17,7 +17,11 @@
 #include <thread>
 #include <vector>
 
+struct sctl_amd_comm;
 namespace sctl_amd {
+// comm.hip
+int comm_gather_to_device(sctl_amd_comm* c, const void* local, int64_t nbytes, void** dbuf, size_t* dcap, std::vector<int64_t>* bytes_of_rank,
+                          char* (*stage_take)(void*, size_t), void* stage, hipStream_t st);
 // centered.hip
 template <class R>
 hipError_t eval_centered(int kernel_id, int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* xn, const R* f, R* v_trg, double scale, int mode,
@@ -281,7 +285,7 @@ struct StreamGuard {
 // Why not hipMemcpyAsync straight from the caller's pageable arrays: callers reuse their arrays (SCTL keeps one density
 // vector and rewrites it every solver iteration), and with ROCm 7.2 on this platform an H2D copy from a pageable buffer
 // whose CONTENTS changed since the previous copy from the SAME address delivered the old contents about once per
-// thousand transfers (tools/dbg stress: 3-4 of 3000 with one reused host buffer, 0 of 3000 with alternating buffers,
+// thousand transfers (tools/ubench/h2d_reuse.hip stresses this; in the library: 3-4 of 3000 with one reused host buffer, 0 of 3000 with alternating buffers,
 // with or without SDMA, with hipMemcpy as well as hipMemcpyAsync).  A CPU memcpy into pinned memory plus a DMA from
 // there costs ~1.5 % at 2^20 points and removes the hazard.
 struct PinnedBuf {
@@ -300,6 +304,10 @@ struct PinnedBuf {
     char* q = p + used;
     used += (bytes + 255) & ~(size_t)255;
     return q;
+  }
+  static char* reserve_and_take(void* self, size_t bytes) {   // one slice holding `bytes` (for comm_gather_to_device); nullptr if out of memory
+    PinnedBuf* b = (PinnedBuf*)self;
+    return b->reserve(bytes) == hipSuccess ? b->take(bytes) : nullptr;
   }
 };
 inline size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
@@ -519,8 +527,7 @@ int sctl_amd_register_kernel(const sctl_amd_kernel_desc* d) {
   if (e->k0 < 1 || e->k1 < 1 || (e->nd != 0 && e->nd != 3) || e->ctx_bytes < 0 || e->ctx_bytes > (int)sizeof(KerCtx))
     return fail(SCTL_AMD_ERR_BAD_ARGUMENT, std::string("kernel '") + d->name + "': dimensions or context size out of range");
   for (int m = 0; m < kNumMode; m++) {
-    if (!(e->acc_factor[m] > 0) || !e->matrix_f64[m] || !e->matrix_f32[m] || !e->matrix_batch_f64[m] || !e->matrix_batch_f32[m] || !e->lists_f64[m][0] ||
-        !e->lists_f64[m][1] || !e->lists_f32[m][0] || !e->lists_f32[m][1])
+    if (!(e->acc_factor[m] > 0) || !e->matrix_f64[m] || !e->matrix_f32[m] || !e->matrix_batch_f64[m] || !e->matrix_batch_f32[m] || !e->lists_f64[m] || !e->lists_f32[m])
       return fail(SCTL_AMD_ERR_BAD_ARGUMENT, std::string("kernel '") + d->name + "': incomplete launch table");
     for (int t = 0; t < kNumT; t++)
       if (!e->eval_f64[m][t] || !e->eval_f32[m][t]) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, std::string("kernel '") + d->name + "': incomplete launch table");
@@ -859,8 +866,10 @@ int sctl_amd_op_set_target_normals(sctl_amd_op* op, const void* n_trg) {
   return rc;
 }
 
-// far field (+ the attached near field when f_near != nullptr) of one density, potential back to the host once
-static int op_eval_impl(sctl_amd_op* op, const void* v_src, const void* f_near, void* v_trg, int accumulate, int digits, const void* ctx, int ctx_bytes) {
+// far field (+ the attached near field when f_near != nullptr) of one density, potential back to the host once.
+// comm != nullptr: v_src is this rank's share of the density; all ranks' shares are gathered on the device (rank order).
+static int op_eval_impl(sctl_amd_op* op, const void* v_src, const void* f_near, void* v_trg, int accumulate, int digits, const void* ctx, int ctx_bytes,
+                        sctl_amd_comm* comm = nullptr, int64_t ns_local = 0) {
   if (!op) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "null handle");
   const KernelEntry& k = *op->k;
   if (f_near && op->near.empty()) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "no near-field operator attached: call sctl_amd_op_set_near first");
@@ -868,21 +877,30 @@ static int op_eval_impl(sctl_amd_op* op, const void* v_src, const void* f_near, 
     return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "the attached near-field operator has another potential dimension than the far field delivers");
   if (k.ctx_bytes != 0 && (ctx_bytes != k.ctx_bytes || !ctx))
     return fail(SCTL_AMD_ERR_BAD_CONTEXT, std::string(k.name) + " needs a context blob of " + std::to_string(k.ctx_bytes) + " bytes");
-  if ((op->Ns > 0 && !v_src) || (op->Nt > 0 && !v_trg)) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "null density or potential array");
+  if ((!comm && op->Ns > 0 && !v_src) || (comm && ns_local > 0 && !v_src) || (op->Nt > 0 && !v_trg)) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "null density or potential array");
   const size_t rs = (op->real == SCTL_AMD_F64) ? 8 : 4;
   const int64_t Ns = op->Ns;
   const size_t near_bytes = f_near ? (size_t)op->near_f_len * rs : 0;
   return op_for_each_device(op, [&](OpDevice& d) -> int {
     const int64_t nt = d.t1 - d.t0;
     const size_t vbytes = (size_t)nt * k.k1 * rs;
-    if (nt == 0) return SCTL_AMD_OK;
+    if (nt == 0 && !comm) return SCTL_AMD_OK;      // (a rank without targets still takes part in the gather)
     const size_t g = (size_t)(&d - op->devs.data());
     DeviceScope dev_scope_8(d.device);
     HIP_TRY(dev_scope_8.err);
     HIP_TRY(grow(&d.f, &d.cap_f, (size_t)Ns * k.k0 * rs));
     HIP_TRY(grow(&d.v, &d.cap_v, vbytes));
-    HIP_TRY(d.stage.reserve(pad256((size_t)Ns * k.k0 * rs) + pad256(near_bytes) + pad256(vbytes)));
-    HIP_TRY(upload(d.f, v_src, (size_t)Ns * k.k0 * rs, d.stage, d.st));
+    if (comm) {   // every rank's density into d.f, in the rank order the sources were gathered in
+      std::vector<int64_t> got;
+      const int rc = comm_gather_to_device(comm, v_src, ns_local * k.k0 * (int64_t)rs, &d.f, &d.cap_f, &got, &PinnedBuf::reserve_and_take, &d.stage, d.st);
+      if (rc) return rc;
+      int64_t tot = 0;
+      for (int64_t b : got) tot += b;
+      if (tot != Ns * k.k0 * (int64_t)rs) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "the ranks' densities do not match the sources gathered by sctl_amd_op_set_sources_dist");
+      HIP_TRY(hipStreamSynchronize(d.st));   // the staging slice is reused below
+    }
+    HIP_TRY(d.stage.reserve(pad256(comm ? 0 : (size_t)Ns * k.k0 * rs) + pad256(near_bytes) + pad256(vbytes)));
+    if (!comm) HIP_TRY(upload(d.f, v_src, (size_t)Ns * k.k0 * rs, d.stage, d.st));
     if (near_bytes) HIP_TRY(upload(op->near_f[g], f_near, near_bytes, d.stage, d.st));
     if (op->have_weights) {   // density x quadrature weights (boundary_integral.txx:1040-1052)
       const unsigned nb = (unsigned)((Ns * k.k0 + kBlock - 1) / kBlock);
@@ -944,6 +962,38 @@ static int op_eval_impl(sctl_amd_op* op, const void* v_src, const void* f_near, 
 
 int sctl_amd_op_eval(sctl_amd_op* op, const void* v_src, void* v_trg, int accumulate, int digits, const void* ctx, int ctx_bytes) {
   return op_eval_impl(op, v_src, nullptr, v_trg, accumulate, digits, ctx, ctx_bytes);
+}
+
+// ---- rank-parallel form: every rank owns some targets and some sources (ParticleFMM::EvalDirect under MPI, fmm-wrapper.txx:504-561) ----
+int sctl_amd_op_set_sources_dist(sctl_amd_op* op, sctl_amd_comm* comm, int64_t Ns_local, const void* r_src, const void* n_src) {
+  if (!op || !comm || Ns_local < 0 || (Ns_local > 0 && !r_src)) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "bad source arguments");
+  if (op->devs.size() != 1) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "a rank-parallel operator lives on ONE device per rank");
+  if (Ns_local > 0 && op->k->nd > 0 && !n_src) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, std::string(op->k->name) + " needs source normals (n_src is null)");
+  const size_t rs = (op->real == SCTL_AMD_F64) ? 8 : 4;
+  OpDevice& d = op->devs[0];
+  op->have_weights = false;
+  DeviceScope scope(d.device);
+  HIP_TRY(scope.err);
+  std::vector<int64_t> got, gotn;
+  int rc = comm_gather_to_device(comm, r_src, Ns_local * 3 * (int64_t)rs, &d.xs, &d.cap_xs, &got, &PinnedBuf::reserve_and_take, &d.stage, d.st);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(d.st));
+  int64_t tot = 0;
+  for (int64_t b : got) tot += b;
+  op->Ns = tot / (3 * (int64_t)rs);
+  if (op->k->nd) {
+    rc = comm_gather_to_device(comm, n_src, Ns_local * op->k->nd * (int64_t)rs, &d.xn, &d.cap_xn, &gotn, &PinnedBuf::reserve_and_take, &d.stage, d.st);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(d.st));
+  }
+  return SCTL_AMD_OK;
+}
+
+int sctl_amd_op_eval_dist(sctl_amd_op* op, sctl_amd_comm* comm, int64_t Ns_local, const void* v_src_local, void* v_trg, int accumulate, int digits,
+                          const void* ctx, int ctx_bytes) {
+  if (!op || !comm || Ns_local < 0) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "null handle or communicator");
+  if (op->devs.size() != 1) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "a rank-parallel operator lives on ONE device per rank");
+  return op_eval_impl(op, v_src_local, nullptr, v_trg, accumulate, digits, ctx, ctx_bytes, comm, Ns_local);
 }
 
 int sctl_amd_op_eval_potential(sctl_amd_op* op, const void* v_src_far, const void* f_near, void* v_trg, int accumulate, int digits, const void* ctx,
@@ -1062,6 +1112,11 @@ void sctl_amd_counters(int64_t* pair_interactions, int64_t* sctl_flops) {
 }
 void sctl_amd_reset_counters(void) { g_pairs = 0; g_flops = 0; }
 void sctl_amd_trim(void) { workspace_release_all(); }
+int sctl_amd_set_debug(int flags) {
+  static std::atomic<int> cur{0};
+  workspace_poison((flags & SCTL_AMD_DEBUG_POISON_SCRATCH) != 0);
+  return cur.exchange(flags);
+}
 
 int sctl_amd_eval_plan(int kernel, int real, int64_t Nt, int64_t Ns, int64_t Nt_whole, int digits, int* trg_per_lane, int* src_splits,
                        int64_t* workgroups, int64_t* workspace_bytes) {

@@ -22,7 +22,7 @@ namespace {
 
 struct sctl_amd_lists {
   const sctl_amd::KernelEntry* k = nullptr;
-  int real = 0, device = 0, t_idx = 0;      // t_idx: 0 = one target per lane, 1 = two
+  int real = 0, device = 0;
   int64_t Nt = 0, Ns = 0, nitems = 0, nranges = 0, pairs = 0;
   void *d_items = nullptr, *d_ranges = nullptr;
   // host-pointer evaluation: device copies of the caller's arrays and pinned staging, grown on demand
@@ -76,22 +76,24 @@ int sctl_amd_lists_create(int kernel, int real, int device, int64_t nlists, cons
   }
   for (const Group& g : groups)
     if (g.nranges > INT32_MAX) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "too many lists for one target range");
-  // two targets per lane halve the LDS reads per pair (eval_kernel.hpp) but waste lanes on small boxes: from ~96 targets per box on
-  const int t_idx = (!groups.empty() && trg_in_groups / (int64_t)groups.size() >= 96) ? 1 : 0;
-  const int64_t per_item = (int64_t)kListWave * (t_idx ? 2 : 1);
+  (void)trg_in_groups;
   std::vector<size_t> gorder(groups.size());
   std::iota(gorder.begin(), gorder.end(), (size_t)0);
   std::stable_sort(gorder.begin(), gorder.end(), [&](size_t a, size_t b) { return groups[a].nsrc > groups[b].nsrc; });   // long items first: short tail
   std::vector<ListItem> items;
   for (size_t gi : gorder) {
     const Group& g = groups[gi];
-    for (int64_t t = 0; t < g.nt; t += per_item)
-      items.push_back(ListItem{g.t0 + t, (int32_t)std::min<int64_t>(per_item, g.nt - t), (int32_t)g.nranges, g.first_range});
+    // 128-target items (two targets per lane: half the LDS reads per pair); a remainder of at most 64 gets a one-target-per-lane item
+    for (int64_t t = 0; t < g.nt;) {
+      const int64_t left = g.nt - t, n = left > kListWave ? std::min<int64_t>(left, 2 * kListWave) : left;
+      items.push_back(ListItem{g.t0 + t, (int32_t)n, (int32_t)g.nranges, g.first_range});
+      t += n;
+    }
   }
   if (items.size() > 0x7fffffffu) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "too many work items for one launch");
 
   sctl_amd_lists* p = new sctl_amd_lists;
-  p->k = k; p->real = real; p->device = device; p->t_idx = t_idx; p->Nt = Nt; p->Ns = Ns;
+  p->k = k; p->real = real; p->device = device; p->Nt = Nt; p->Ns = Ns;
   p->nitems = (int64_t)items.size(); p->nranges = (int64_t)ranges.size(); p->pairs = pairs;
   *out = p;
   if (items.empty()) return SCTL_AMD_OK;       // nothing to do: legal, and needs no device
@@ -129,12 +131,11 @@ void sctl_amd_lists_destroy(sctl_amd_lists* p) {
   delete p;
 }
 
-int sctl_amd_lists_info(const sctl_amd_lists* p, int64_t* pairs, int64_t* work_items, int64_t* source_ranges, int* trg_per_lane) {
+int sctl_amd_lists_info(const sctl_amd_lists* p, int64_t* pairs, int64_t* work_items, int64_t* source_ranges) {
   if (!p) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "null handle");
   if (pairs) *pairs = p->pairs;
   if (work_items) *work_items = p->nitems;
   if (source_ranges) *source_ranges = p->nranges;
-  if (trg_per_lane) *trg_per_lane = p->t_idx ? 2 : 1;
   return SCTL_AMD_OK;
 }
 
@@ -152,11 +153,11 @@ int sctl_amd_lists_eval_device(sctl_amd_lists* p, const void* r_trg, const void*
   if (p->real == SCTL_AMD_F64) {
     ListArgs<double> a{(const ListItem*)p->d_items, (const ListRange*)p->d_ranges, (const double*)r_trg, (const double*)r_src, (const double*)n_src,
                        (const double*)v_src, (double*)v_trg, scale, make_ctx(k, ctx)};
-    k.lists_f64[mode][p->t_idx](a, p->nitems, (hipStream_t)stream);
+    k.lists_f64[mode](a, p->nitems, (hipStream_t)stream);
   } else {
     ListArgs<float> a{(const ListItem*)p->d_items, (const ListRange*)p->d_ranges, (const float*)r_trg, (const float*)r_src, (const float*)n_src,
                       (const float*)v_src, (float*)v_trg, (float)scale, make_ctx(k, ctx)};
-    k.lists_f32[mode][p->t_idx](a, p->nitems, (hipStream_t)stream);
+    k.lists_f32[mode](a, p->nitems, (hipStream_t)stream);
   }
   LISTS_TRY(hipGetLastError());
   count_work(p->pairs, k);

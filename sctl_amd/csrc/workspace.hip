@@ -1,5 +1,6 @@
 #include "workspace.hpp"
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -8,6 +9,7 @@ namespace sctl_amd {
 namespace {
 struct Block { void* p = nullptr; size_t cap = 0; };
 std::mutex g_mu;
+std::atomic<bool> g_poison{false};
 std::map<std::pair<int, hipStream_t>, Block>& blocks() {   // leaked on purpose: no HIP calls from static destructors
   static auto* m = new std::map<std::pair<int, hipStream_t>, Block>;
   return *m;
@@ -28,8 +30,11 @@ hipError_t workspace_acquire(hipStream_t st, size_t bytes, void** base) {
     b.cap = want;
   }
   *base = b.p;
+  if (g_poison.load() && bytes) return hipMemsetAsync(b.p, 0xFF, bytes, st);
   return hipSuccess;
 }
+
+void workspace_poison(bool on) { g_poison.store(on); }
 
 void workspace_forget(hipStream_t st) {
   int dev = 0;

@@ -4,7 +4,7 @@
 // libsctl_amd.so gets) the SECOND allocation of a block the pool had just handed out and taken back returned memory
 // through which a kernel's partial sums were lost — ParticleFMM::Eval called twice on one object gave a wrong second
 // result in about half of the runs at N = 3000 and in every run at N = 5000, for every placement of stream
-// synchronisations around the pool calls, and never with plain hipMalloc (tools/dbg/fmm_repeat.cpp).  Python callers did
+// synchronisations around the pool calls, and never with plain hipMalloc (the driver is tests/cpp/fmm_repeat.cpp, run by tests/test_cpp_host.py).  Python callers did
 // not see it because PyTorch brings the ROCm 7.0 runtime into the process.
 //
 // Instead: one grow-only hipMalloc'd block per (device, stream).  A call acquires the block of its stream once and
@@ -20,6 +20,10 @@ namespace sctl_amd {
 
 // Base pointer of at least `bytes` of scratch for work enqueued on `st` of the current device (contents undefined).
 hipError_t workspace_acquire(hipStream_t st, size_t bytes, void** base);
+// Debug aid (sctl_amd_set_debug bit 0): every acquire first fills the block with 0xFF bytes (NaN in fp64 and fp32) on the caller's
+// stream, so that a kernel reading scratch it did not write in THIS call poisons its result instead of silently reusing the
+// (plausible) numbers the previous call left there.
+void workspace_poison(bool on);
 // Drop the block of a stream that is about to be destroyed / every block of every device (both wait for the device).
 void workspace_forget(hipStream_t st);
 void workspace_release_all();

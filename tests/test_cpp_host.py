@@ -85,6 +85,31 @@ def test_repeated_eval_on_one_object_is_bit_identical(tmp_path, n, reps, sleep_u
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,which", [(3000, "stokes"), (5000, "stokes"), (1 << 18, "laplace")])
+def test_repeated_eval_with_changing_problems_and_poisoned_scratch(tmp_path, O, n, which):
+    """The discriminating form of the test above: every evaluation on the one object is a DIFFERENT problem (new density, fewer
+    targets), the scratch block is filled with NaN before each use (sctl_amd_set_debug), and every result is compared with the
+    oracle — stale scratch cannot pass as a right answer.  2^18 Laplace points take the tile-centred path (sort buffers + 16
+    partial-sum slabs in the arena); the Stokes sizes are those of the original memory-pool fault."""
+    exe = _build(tmp_path, "fmm_repeat")
+    out = str(tmp_path / "u.bin")
+    reps = 4
+    p = subprocess.run([exe, str(n), str(reps), "0", which, out, "vary"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    g = Rand48(0)
+    xt, xs, xn = g.drand48(n * 3) - 0.5, g.drand48(n * 3) - 0.5, g.drand48(n * 3) - 0.5
+    name, k0 = ("Laplace3D-FxU", 1) if which == "laplace" else ("Stokes3D-DxU", 3)
+    f = g.drand48(n * k0) - 0.5
+    for r in range(reps):
+        u = _read_vector("%s.r%d" % (out, r))
+        nt = n - 101 * r
+        assert u.size == nt * k0 and np.all(np.isfinite(u))
+        sel = np.arange(0, nt, max(1, nt // 300))
+        ref = O.eval(name, xt.reshape(-1, 3)[sel].ravel().copy(), xs, xn if which == "stokes" else None, f * (r + 1) + 0.01 * r).reshape(sel.size, k0)
+        assert rel_l2(u.reshape(nt, k0)[sel], ref) <= 1e-12, (r, rel_l2(u.reshape(nt, k0)[sel], ref))
+
+
+@pytest.mark.gpu
 def test_centred_path_from_a_cpp_process(tmp_path, O):
     """Laplace single layer at 2^18 points through ParticleFMM from C++ (tile-centred path on /opt/rocm's runtime): repeated
     evaluations bit-identical, equal to the exact kernel (SCTL_AMD_CENTERED=0) to rounding, and right against the oracle."""

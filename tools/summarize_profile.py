@@ -3,6 +3,8 @@
   profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (per-kernel calls / average ns)
   profiles/<tag>_pmc_summary.csv    per-kernel means of the PMC passes (FETCH_SIZE, WRITE_SIZE, SQ_*; one pass each)
   profiles/hbm_traffic.json         HBM bytes per launch of the dominant kernel, read by bench.py for roofline.traffic
+Also derives, for the dominant kernel: the shader clock it ran at (GRBM_GUI_ACTIVE / 8 XCDs / kernel time, MI355X_MICROARCH.md "DVFS give-back")
+and the VALU instructions per wave.
 usage: tools/summarize_profile.py <tag> <workload>"""
 import collections
 import csv
@@ -32,9 +34,12 @@ with open("profiles/%s_kernel_stats.csv" % tag, "w") as fh:
 dominant = max(rows, key=lambda r: float(r["TotalDurationNs"]))
 summ = collections.defaultdict(dict)
 meta = {}
-for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_clk"):
     agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(glob.glob("%s/%s/runc/*_counter_collection.csv" % (P, sub))[0])):
+    found = glob.glob("%s/%s/runc/*_counter_collection.csv" % (P, sub))
+    if not found:
+        continue
+    for r in csv.DictReader(open(found[0])):
         if "at::native" in r["Kernel_Name"]:
             continue
         k = short(r["Kernel_Name"])
@@ -52,8 +57,14 @@ dk = short(dominant["Name"])
 fetch_kb, write_kb = summ[dk]["FETCH_SIZE"][1], summ[dk]["WRITE_SIZE"][1]
 path = "profiles/hbm_traffic.json"
 data = json.load(open(path)) if os.path.exists(path) else {}
+import re
+clk = summ[dk].get("GRBM_GUI_ACTIVE")
+waves, valu = summ[dk].get("SQ_WAVES"), summ[dk].get("SQ_INSTS_VALU")
 data[workload] = {
     "kernel": dk, "kernel_average_ms": float(dominant["AverageNs"]) / 1e6,
+    "symbol_tokens": [t for t in re.findall(r"[A-Za-z_][A-Za-z_0-9]{5,}", dk) if t not in ("double", "float")],   # bench.py checks them against the built library
+    "shader_clock_GHz": (clk[1] / 8 / float(dominant["AverageNs"])) if clk else None,
+    "valu_insts_per_wave": (valu[1] / waves[1]) if (waves and valu) else None,
     "FETCH_SIZE_KB_raw": fetch_kb, "WRITE_SIZE_KB_raw": write_kb,
     "hbm_bytes_per_launch": (2 * fetch_kb + write_kb) * 1024,
     "hbm_bytes_per_launch_uncorrected": (fetch_kb + write_kb) * 1024,
