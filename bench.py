@@ -131,6 +131,37 @@ def bench_near(args):
                                    (nelem, nds * k0, near * k1, op.operator_bytes / 1e9, ntrg), "workgroups": op.workgroups},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": read_traffic("near_apply"),
                          "kernel_ms": k_ms, "note": "algorithmic bytes = sizeof(K_near): 8 B per operator entry, read once per application"}}
+    # Informational, outside the timed region: the whole BoundaryIntegralOp::ComputePotential (boundary_integral.txx:608-614) for this operator
+    # from HOST arrays, as a C++ caller has them — far field (Stokeslet over the elements' nodes as far-field quadrature) + this near field.
+    # "fused": sctl_amd_op_eval_potential (densities down once, near field added to the far field on the device, potential up once);
+    # "two legs": sctl_amd_op_eval, then sctl_amd_near_apply_host (two round trips over PCIe).
+    xs = rng.random(nelem * nds * 3)
+    xt = rng.random(ntrg * 3)
+    wts = rng.random(nelem * nds) * 1e-3
+    far = sctl_amd.DirectOp("Stokes3D-FxU", np.float64)
+    far.set_targets(xt)
+    far.set_sources(xs)
+    far.set_source_weights(wts)
+    far.set_near(k1, np.full(nelem, nds), np.full(nelem, near), K, order, cnt, dsp)
+    Fh = rng.standard_normal(op.density_len)
+    Uh = np.zeros(op.potential_len)
+    far.eval_potential(Fh, Fh, v_trg=Uh, digits=10)
+
+    def wall(fn, reps=5):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        return 1e3 * (time.perf_counter() - t0) / reps
+
+    def two_legs():
+        far.eval(Fh, v_trg=Uh, digits=10)
+        op.apply(Fh, U=Uh)
+    ms_fused = wall(lambda: far.eval_potential(Fh, Fh, v_trg=Uh, digits=10))
+    ms_two = wall(two_legs)
+    line["compute_potential_from_host"] = {"fused_ms": ms_fused, "two_legs_ms": ms_two, "far_pairs": float(ntrg) * nelem * nds,
+                                           "note": "far field Stokes3D-FxU %d x %d at 10 digits + this near field, host arrays in, host array out; not part of `value`" % (ntrg, nelem * nds)}
+    far.close()
     if not args.no_cpu_baseline:
         sample = 256                                           # elements; numpy's BLAS GEMV per element, as Matrix::GEMM at :1101
         Kb = K[:sample * nds * k0 * near * k1].reshape(sample, nds * k0, near * k1)
@@ -387,7 +418,9 @@ def main():
             ms10 = e0.elapsed_time(e1) / 2
             line["at_reference_callers_accuracy"] = {"digits": 10, "ms_per_step": ms10, "value": pairs_per_step / (ms10 * 1e-3),
                                                      "frac": pairs_per_step * fpp / (ms10 * 1e-3) / 1e12 / peak,
-                                                     "rel_l2_vs_full_precision": rel10}
+                                                     "rel_l2_vs_full_precision": rel10,
+                                                     "per_pair_error_bound": "one Newton step from the v_rsq_f64 seed (relative error e <= 2^-24.2): 1/r is off by at most "
+                                                                             "3/8 e^2 <= 2^-49.8 = 1.0e-15 relative, for every digits in 8..14; 1e-12 rel-L2 needs nothing finer"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(kernel, N, dtype)

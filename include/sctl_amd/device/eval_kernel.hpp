@@ -90,20 +90,33 @@ __global__ void __launch_bounds__(kBlock) SCTL_AMD_EVAL_ATTR eval_kernel(const E
   bool always_masked = (ntile < 4);   // few tiles: speculation cannot pay for a repair
   int repairs = 0;
 
+  // One target per lane is what small target counts run (make_plan): few tiles per workgroup, every workgroup of the chip in step,
+  // so nobody covers a tile fill's HBM latency.  Those instantiations fetch the NEXT tile's source into registers while the current
+  // tile is evaluated (155 -> 150 us at 2^14 x 2^14); with more targets per lane the registers are worth more as occupancy.
+  constexpr bool PREFETCH = (T == 1);
+  R px[3] = {0, 0, 0}, pn[3] = {0, 0, 0}, pf[K0];
+#pragma unroll
+  for (int k = 0; k < K0; k++) pf[k] = 0;
+  auto fetch_source = [&](int it) {
+    const int64_t s = s_begin + (int64_t)it * kTile + tid;
+    if (s < s_end) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) px[k] = a.xs[s * 3 + k];
+#pragma unroll
+      for (int k = 0; k < ND; k++) pn[k] = a.xn[s * ND + k];
+#pragma unroll
+      for (int k = 0; k < K0; k++) pf[k] = a.f[s * K0 + k];
+    }
+  };
+  if (PREFETCH && ntile > 0) fetch_source(0);
+
   for (int it = 0; it < ntile; it++) {
-    const int64_t s0 = s_begin + (int64_t)it * kTile;
     const int ns = (it == ntile - 1) ? (int)(len - (int64_t)it * kTile) : kTile;   // wave-uniform
     __syncthreads();   // previous tile fully consumed
+    if (!PREFETCH) fetch_source(it);
     if (tid < ns) {
-      const int64_t s = s0 + tid;
-      R x[3], n[3] = {0, 0, 0}, f[K0], rec[NRECP] = {};
-#pragma unroll
-      for (int k = 0; k < 3; k++) x[k] = a.xs[s * 3 + k];
-#pragma unroll
-      for (int k = 0; k < ND; k++) n[k] = a.xn[s * ND + k];
-#pragma unroll
-      for (int k = 0; k < K0; k++) f[k] = a.f[s * K0 + k];
-      Ker::template pack<R>(rec, x, n, f);
+      R rec[NRECP] = {};
+      Ker::template pack<R>(rec, px, pn, pf);
 #pragma unroll
       for (int v = 0; v < NV; v++) {
         V w;
@@ -112,6 +125,7 @@ __global__ void __launch_bounds__(kBlock) SCTL_AMD_EVAL_ATTR eval_kernel(const E
         tile[tid * NV + v] = w;
       }
     }
+    if (PREFETCH && it + 1 < ntile) fetch_source(it + 1);   // in flight during this tile's arithmetic
     __syncthreads();
 
     // Per-tile accumulators (folded into the running sums once per tile: two-level summation, which also bounds

@@ -12,7 +12,7 @@ constexpr int kNumMode = 3;                    // rsqrt refinement: seed, Newton
 
 template <class R> using EvalLaunch = void (*)(const EvalArgs<R>&, dim3 grid, hipStream_t);
 template <class R> using MatrixBatchLaunch = void (*)(const MatTile* tiles, int64_t ntiles, const R* xt, const R* xs, const R* xn, R* M, R scale, const KerCtx&, hipStream_t);
-template <class R> using ListsLaunch = void (*)(const ListArgs<R>&, int64_t nitems, hipStream_t);
+template <class R> using ListsLaunch = void (*)(const ListArgs<R>&, int64_t nblocks, hipStream_t);
 template <class R> using MatrixLaunch = void (*)(int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* xn, R* M, R scale, const KerCtx&, dim3 grid, hipStream_t);
 
 struct KernelEntry {
@@ -43,8 +43,8 @@ template <class Ker, class R, int MODE> void launch_matrix_batch(const MatTile* 
   hipLaunchKernelGGL((matrix_batch_kernel<Ker, R, MODE>), dim3((unsigned)ntiles), dim3(kBlock), 0, st, tiles, xt, xs, xn, M, scale, ctx);
 }
 
-template <class Ker, class R, int MODE> void launch_lists(const ListArgs<R>& a, int64_t nitems, hipStream_t st) {
-  hipLaunchKernelGGL((lists_kernel<Ker, R, MODE>), dim3((unsigned)nitems), dim3(kListWave), 0, st, a);
+template <class Ker, class R, int MODE> void launch_lists(const ListArgs<R>& a, int64_t nblocks, hipStream_t st) {
+  hipLaunchKernelGGL((lists_kernel<Ker, R, MODE>), dim3((unsigned)nblocks), dim3(kListWave), 0, st, a);
 }
 
 template <class Ker> KernelEntry make_entry(int ctx_bytes) {

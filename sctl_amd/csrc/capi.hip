@@ -1083,6 +1083,7 @@ int sctl_amd_op_set_near(sctl_amd_op* op, int src_dim, int trg_dim, int64_t Nele
       const size_t at = Kg.size();
       Kg.resize(at + (size_t)rows * cols.size() * piece);
       char* out = Kg.data() + at;
+      if ((int64_t)cols.size() == nc) { std::memcpy(out, blk, (size_t)rows * row_in); continue; }   // the whole block lives here
       for (int64_t r = 0; r < rows; r++)
         for (int64_t j : cols) { std::memcpy(out, blk + (size_t)r * row_in + (size_t)j * piece, piece); out += piece; }
     }

@@ -23,7 +23,8 @@ namespace {
 struct sctl_amd_lists {
   const sctl_amd::KernelEntry* k = nullptr;
   int real = 0, device = 0;
-  int64_t Nt = 0, Ns = 0, nitems = 0, nranges = 0, pairs = 0;
+  int64_t Nt = 0, Ns = 0, nitems = 0, nranges = 0, pairs = 0, nblocks = 0;
+  int32_t xcd_first[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   void *d_items = nullptr, *d_ranges = nullptr;
   // host-pointer evaluation: device copies of the caller's arrays and pinned staging, grown on demand
   hipStream_t st = nullptr;
@@ -77,24 +78,44 @@ int sctl_amd_lists_create(int kernel, int real, int device, int64_t nlists, cons
   for (const Group& g : groups)
     if (g.nranges > INT32_MAX) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "too many lists for one target range");
   (void)trg_in_groups;
-  std::vector<size_t> gorder(groups.size());
-  std::iota(gorder.begin(), gorder.end(), (size_t)0);
-  std::stable_sort(gorder.begin(), gorder.end(), [&](size_t a, size_t b) { return groups[a].nsrc > groups[b].nsrc; });   // long items first: short tail
+  // Eight shares, one per XCD (lists_kernel.hpp): contiguous runs of target ranges in the caller's order — a tree code lists its
+  // boxes along a space-filling curve, so a run is a compact region whose boxes stream the same sources — each with 1/8 of the
+  // pair count.  Inside a share: long items first (a short tail), coarsely — by the number of 4096-source chunks —, neighbours
+  // otherwise staying neighbours.
   std::vector<ListItem> items;
-  for (size_t gi : gorder) {
-    const Group& g = groups[gi];
-    // 128-target items (two targets per lane: half the LDS reads per pair); a remainder of at most 64 gets a one-target-per-lane item
-    for (int64_t t = 0; t < g.nt;) {
-      const int64_t left = g.nt - t, n = left > kListWave ? std::min<int64_t>(left, 2 * kListWave) : left;
-      items.push_back(ListItem{g.t0 + t, (int32_t)n, (int32_t)g.nranges, g.first_range});
-      t += n;
+  int32_t xcd_first[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  {
+    size_t g0 = 0;
+    int64_t done = 0;
+    for (int x = 0; x < 8; x++) {
+      size_t g1 = g0;
+      const int64_t upto = pairs / 8 * (x + 1) + (x == 7 ? pairs % 8 : 0);
+      while (g1 < groups.size() && (x == 7 || done + groups[g1].nt * groups[g1].nsrc / 2 < upto)) { done += groups[g1].nt * groups[g1].nsrc; g1++; }
+      std::vector<size_t> gorder(g1 - g0);
+      std::iota(gorder.begin(), gorder.end(), g0);
+      std::stable_sort(gorder.begin(), gorder.end(), [&](size_t a, size_t b) { return (groups[a].nsrc >> 12) > (groups[b].nsrc >> 12); });
+      for (size_t gi : gorder) {
+        const Group& g = groups[gi];
+        // 128-target items (two targets per lane: half the LDS reads per pair); a remainder of at most 64 gets a one-target-per-lane item
+        for (int64_t t = 0; t < g.nt;) {
+          const int64_t left = g.nt - t, n = left > kListWave ? std::min<int64_t>(left, 2 * kListWave) : left;
+          items.push_back(ListItem{g.t0 + t, (int32_t)n, (int32_t)g.nranges, g.first_range});
+          t += n;
+        }
+      }
+      if (items.size() > 0x7ffffff0u) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "too many work items for one launch");
+      xcd_first[x + 1] = (int32_t)items.size();
+      g0 = g1;
     }
   }
-  if (items.size() > 0x7fffffffu) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "too many work items for one launch");
+  int64_t longest = 0;
+  for (int x = 0; x < 8; x++) longest = std::max<int64_t>(longest, xcd_first[x + 1] - xcd_first[x]);
+  if (longest * 8 > 0x7fffffff) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "too many work items for one launch");
 
   sctl_amd_lists* p = new sctl_amd_lists;
   p->k = k; p->real = real; p->device = device; p->Nt = Nt; p->Ns = Ns;
-  p->nitems = (int64_t)items.size(); p->nranges = (int64_t)ranges.size(); p->pairs = pairs;
+  p->nitems = (int64_t)items.size(); p->nranges = (int64_t)ranges.size(); p->pairs = pairs; p->nblocks = longest * 8;
+  std::memcpy(p->xcd_first, xcd_first, sizeof xcd_first);
   *out = p;
   if (items.empty()) return SCTL_AMD_OK;       // nothing to do: legal, and needs no device
   const int avail = device_count_quiet();
@@ -151,13 +172,15 @@ int sctl_amd_lists_eval_device(sctl_amd_lists* p, const void* r_trg, const void*
   const int mode = mode_for(p->real, digits);
   const double scale = k.scale / k.acc_factor[mode];
   if (p->real == SCTL_AMD_F64) {
-    ListArgs<double> a{(const ListItem*)p->d_items, (const ListRange*)p->d_ranges, (const double*)r_trg, (const double*)r_src, (const double*)n_src,
+    ListArgs<double> a{{0}, (const ListItem*)p->d_items, (const ListRange*)p->d_ranges, (const double*)r_trg, (const double*)r_src, (const double*)n_src,
                        (const double*)v_src, (double*)v_trg, scale, make_ctx(k, ctx)};
-    k.lists_f64[mode](a, p->nitems, (hipStream_t)stream);
+    std::memcpy(a.xcd_first, p->xcd_first, sizeof a.xcd_first);
+    k.lists_f64[mode](a, p->nblocks, (hipStream_t)stream);
   } else {
-    ListArgs<float> a{(const ListItem*)p->d_items, (const ListRange*)p->d_ranges, (const float*)r_trg, (const float*)r_src, (const float*)n_src,
+    ListArgs<float> a{{0}, (const ListItem*)p->d_items, (const ListRange*)p->d_ranges, (const float*)r_trg, (const float*)r_src, (const float*)n_src,
                       (const float*)v_src, (float*)v_trg, (float)scale, make_ctx(k, ctx)};
-    k.lists_f32[mode](a, p->nitems, (hipStream_t)stream);
+    std::memcpy(a.xcd_first, p->xcd_first, sizeof a.xcd_first);
+    k.lists_f32[mode](a, p->nblocks, (hipStream_t)stream);
   }
   LISTS_TRY(hipGetLastError());
   count_work(p->pairs, k);

@@ -60,7 +60,7 @@ int main(int argc, char** argv) {
   fmm.SetAccuracy(16);
   fmm.SetKernels(ker_m2l, ker_m2l, ker_sl);
   fmm.AddTrg("Velocity", ker_m2l, ker_sl);
-  fmm.AddSrc("DoubleLayer", ker_m2l, ker_m2l);
+  fmm.AddSrc("DoubleLayer", ker_dl, ker_dl);
   fmm.AddSrc("SingleLayer", ker_sl, ker_sl);
   fmm.SetKernelS2T("DoubleLayer", "Velocity", ker_dl);
   fmm.SetKernelS2T("SingleLayer", "Velocity", ker_sl);

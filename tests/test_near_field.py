@@ -45,7 +45,17 @@ def dims(O, c):
 IDS = ["%s-%s" % (c["kernel"], c["key"]) for c in CASES]
 
 
+_FREE_CACHE = {}
+
+
 def matrix_free_part(O, case, arrs, xt, xnt, xs, xn, w, f):
+    """Cached per case (several tests and device counts ask for the same one)."""
+    if case["key"] not in _FREE_CACHE:
+        _FREE_CACHE[case["key"]] = _matrix_free_part(O, case, arrs, xt, xnt, xs, xn, w, f)
+    return _FREE_CACHE[case["key"]].copy()
+
+
+def _matrix_free_part(O, case, arrs, xt, xnt, xs, xn, w, f):
     """Contribution of the matrix-free element list of a two-list case (oracle/ref_near_shim.cpp: FreePatchElemList) to the
     potential, in numpy: per element e of that list and near target t,  u[t][k1] += 0.25 sum_{j,k0} f[j][k0] g_j M[(j,k0)][k1],
     g_j = w_j (1 + 0.5 / (1 + |x_t - x_j|^2 / rad^2)), M = scaled kernel matrix of the element's nodes at x_t (dotted with the
@@ -75,7 +85,8 @@ def matrix_free_part(O, case, arrs, xt, xnt, xs, xn, w, f):
         assert j1 - j0 == arrs["elem_nds_cnt"][e] and arrs["K_near_cnt"][e] == 0
         for entry in range(int(near_dsp[e]), int(near_dsp[e + 1])):
             t = trg_of_entry[entry]
-            M = O.kernel_matrix(case["kernel"], X[t].copy(), xs[j0 * 3:j1 * 3].copy(), xn[j0 * 3:j1 * 3].copy()).reshape(j1 - j0, k0, k1f)
+            # nthreads=1: hundreds of tiny calls; waking a 128-thread OpenMP team for each costs ~0.1 s on the GPU box's host
+            M = O.kernel_matrix(case["kernel"], X[t].copy(), xs[j0 * 3:j1 * 3].copy(), xn[j0 * 3:j1 * 3].copy(), nthreads=1).reshape(j1 - j0, k0, k1f)
             r2 = ((X[t] - xs[j0 * 3:j1 * 3].reshape(-1, 3)) ** 2).sum(1)
             g = w[j0:j1] * (1 + 0.5 / (1 + r2 / rad ** 2))
             if dot:

@@ -5,7 +5,7 @@
   profiles/hbm_traffic.json         HBM bytes per launch of the dominant kernel, read by bench.py for roofline.traffic
 Also derives, for the dominant kernel: the shader clock it ran at (GRBM_GUI_ACTIVE / 8 XCDs / kernel time, MI355X_MICROARCH.md "DVFS give-back")
 and the VALU instructions per wave.
-usage: tools/summarize_profile.py <tag> <workload>"""
+usage: tools/summarize_profile.py <tag> <workload> [<substring the dominant kernel's name must contain>]"""
 import collections
 import csv
 import glob
@@ -19,7 +19,7 @@ os.makedirs("profiles", exist_ok=True)
 
 
 def short(name):
-    name = name.split("(")[0]
+    name = name.replace("(anonymous namespace)::", "").split("(")[0]
     for pre in ("void ", "sctl_amd::", "rocprim::ROCPRIM_400200_NS::detail::"):
         name = name.replace(pre, "")
     return name[:90]
@@ -31,7 +31,8 @@ with open("profiles/%s_kernel_stats.csv" % tag, "w") as fh:
     fh.write("kernel,calls,total_ns,average_ns,percentage\n")
     for r in rows:
         fh.write("%s,%s,%s,%s,%s\n" % (short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]))
-dominant = max(rows, key=lambda r: float(r["TotalDurationNs"]))
+want = sys.argv[3] if len(sys.argv) > 3 else ""
+dominant = max((r for r in rows if want in r["Name"]), key=lambda r: float(r["TotalDurationNs"]))
 summ = collections.defaultdict(dict)
 meta = {}
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_clk"):
