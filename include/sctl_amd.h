@@ -186,7 +186,7 @@ void sctl_amd_op_destroy(sctl_amd_op* op);
  * this rank, or -1 for a host-only communicator (the host collectives work without any GPU).  flags: SCTL_AMD_COMM_SOCKETS_ONLY
  * keeps RCCL out even when it could be used. */
 typedef struct sctl_amd_comm sctl_amd_comm;
-enum { SCTL_AMD_COMM_SOCKETS_ONLY = 1 };
+enum { SCTL_AMD_COMM_SOCKETS_ONLY = 1, SCTL_AMD_COMM_FORCE_RCCL = 2 /* size == 1 only: build a one-rank RCCL communicator (for sctl_amd_comm_selftest) */ };
 enum { SCTL_AMD_COMM_SOCKETS = 0, SCTL_AMD_COMM_RCCL = 1 };   /* sctl_amd_comm_info: transport of the data path */
 int sctl_amd_comm_create(int rank, int size, const char* master_addr, int master_port, int device, int flags, sctl_amd_comm** comm);
 int sctl_amd_comm_info(const sctl_amd_comm* comm, int* rank, int* size, int* device, int* transport);
@@ -194,6 +194,9 @@ int sctl_amd_comm_info(const sctl_amd_comm* comm, int* rank, int* size, int* dev
  * the concatenation in rank order (at most recv_capacity bytes) and bytes_of_rank[size] the contributions. */
 int sctl_amd_comm_allgatherv_host(sctl_amd_comm* comm, const void* send, int64_t send_bytes, void* recv, int64_t recv_capacity, int64_t* bytes_of_rank);
 int sctl_amd_comm_barrier(sctl_amd_comm* comm);
+/* Checks the RCCL data path: every rank sends `bytes` bytes to its right neighbour (itself, with one rank) with the grouped
+ * ncclSend / ncclRecv the gathers use, and verifies what arrives.  Collective.  BAD_ARGUMENT if the data path is the sockets. */
+int sctl_amd_comm_selftest(sctl_amd_comm* comm, int64_t bytes);
 void sctl_amd_comm_destroy(sctl_amd_comm* comm);
 /* Collective forms of sctl_amd_op_set_sources / sctl_amd_op_eval for an operator with ONE device (this rank's): the operator's
  * sources become the concatenation, in rank order, of all ranks' Ns_local sources (HOST arrays); eval_dist gathers the ranks'

@@ -27,8 +27,8 @@ class Comm {
   Comm() {}
   static Comm Self() { return Comm(); }
   static Comm World() {
-    static Comm world = FromEnvironment();
-    return world;
+    static Comm* world = new Comm(FromEnvironment());   // never destroyed: its RCCL communicator must not outlive the HIP runtime's own teardown
+    return *world;
   }
   Integer Rank() const { return h_ ? h_->rank : 0; }
   Integer Size() const { return h_ ? h_->size : 1; }

@@ -26,7 +26,7 @@ SYMBOLS = ["sctl_amd_version", "sctl_amd_last_error", "sctl_amd_device_count", "
            "sctl_amd_eval_plan", "sctl_amd_eval_path", "sctl_amd_op_create", "sctl_amd_op_set_targets",
            "sctl_amd_op_set_sources", "sctl_amd_op_set_source_weights", "sctl_amd_op_set_target_normals", "sctl_amd_op_eval", "sctl_amd_op_destroy", "sctl_amd_near_create", "sctl_amd_near_apply_host",
            "sctl_amd_near_apply_device", "sctl_amd_near_info", "sctl_amd_near_destroy", "sctl_amd_num_kernels", "sctl_amd_register_kernel", "sctl_amd_load_plugin",
-           "sctl_amd_set_debug", "sctl_amd_comm_create", "sctl_amd_comm_info", "sctl_amd_comm_allgatherv_host", "sctl_amd_comm_barrier", "sctl_amd_comm_destroy",
+           "sctl_amd_set_debug", "sctl_amd_comm_create", "sctl_amd_comm_info", "sctl_amd_comm_allgatherv_host", "sctl_amd_comm_barrier", "sctl_amd_comm_selftest", "sctl_amd_comm_destroy",
            "sctl_amd_op_set_sources_dist", "sctl_amd_op_eval_dist", "sctl_amd_op_set_near", "sctl_amd_op_eval_potential", "sctl_amd_lists_create", "sctl_amd_lists_eval_device", "sctl_amd_lists_eval_host", "sctl_amd_lists_info", "sctl_amd_lists_destroy",
            "sctl_amd_eval_lists_device", "sctl_amd_eval_lists_host"]
 

@@ -898,6 +898,7 @@ static int op_eval_impl(sctl_amd_op* op, const void* v_src, const void* f_near, 
       for (int64_t b : got) tot += b;
       if (tot != Ns * k.k0 * (int64_t)rs) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "the ranks' densities do not match the sources gathered by sctl_amd_op_set_sources_dist");
       HIP_TRY(hipStreamSynchronize(d.st));   // the staging slice is reused below
+      if (nt == 0) return SCTL_AMD_OK;       // took part in the gather; owns no targets
     }
     HIP_TRY(d.stage.reserve(pad256(comm ? 0 : (size_t)Ns * k.k0 * rs) + pad256(near_bytes) + pad256(vbytes)));
     if (!comm) HIP_TRY(upload(d.f, v_src, (size_t)Ns * k.k0 * rs, d.stage, d.st));

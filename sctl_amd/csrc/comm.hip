@@ -197,7 +197,20 @@ int sctl_amd_comm_create(int rank, int size, const char* master_addr, int master
   *out = nullptr;
   std::unique_ptr<sctl_amd_comm> c(new sctl_amd_comm);
   c->rank = rank; c->size = size; c->device = device;
-  if (size == 1) { *out = c.release(); return SCTL_AMD_OK; }
+  if (size == 1) {
+    if (flags & SCTL_AMD_COMM_FORCE_RCCL) {   // a one-rank RCCL communicator: lets a one-GPU box exercise the RCCL binding (sctl_amd_comm_selftest)
+      if (device < 0 || device >= device_count_quiet()) return set_error(SCTL_AMD_ERR_NO_DEVICE, "no HIP device for the RCCL communicator");
+      if (!c->rccl.load()) return set_error(SCTL_AMD_ERR_HIP, "librccl could not be loaded");
+      RcclUniqueId id{};
+      DeviceScope scope(device);
+      if (scope.err != hipSuccess) return set_error(SCTL_AMD_ERR_HIP, "hipSetDevice failed for the rank's device");
+      int rc = c->rccl.GetUniqueId(&id);
+      if (rc == 0) rc = c->rccl.CommInitRank(&c->nccl, 1, id, 0);
+      if (rc != 0) { c->nccl = nullptr; return set_error(SCTL_AMD_ERR_HIP, std::string("RCCL initialisation failed: ") + (c->rccl.GetErrorString ? c->rccl.GetErrorString(rc) : "?")); }
+    }
+    *out = c.release();
+    return SCTL_AMD_OK;
+  }
   if (!master_addr || !master_addr[0]) master_addr = "127.0.0.1";
   if (master_port <= 0 || master_port > 65535) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "bad rendezvous port");
   sockaddr_in sa{};
@@ -285,6 +298,35 @@ int sctl_amd_comm_allgatherv_host(sctl_amd_comm* c, const void* send, int64_t se
   if ((int64_t)all.size() > recv_capacity) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "receive buffer too small: " + std::to_string(all.size()) + " bytes arrive");
   if (!all.empty()) std::memcpy(recv, all.data(), all.size());
   return SCTL_AMD_OK;
+}
+
+// RCCL data path check on the communicator's own device: every rank sends `bytes` bytes to its right neighbour and receives from its
+// left one (itself, with one rank) with the grouped ncclSend / ncclRecv the gathers use, and compares what arrived with what the
+// sender holds (a pattern of rank and index).  SCTL_AMD_ERR_BAD_ARGUMENT when the communicator's data path is not RCCL.
+int sctl_amd_comm_selftest(sctl_amd_comm* c, int64_t bytes) {
+  if (!c || bytes <= 0) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "null communicator or empty message");
+  if (!c->nccl) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "this communicator's data path is not RCCL");
+  DeviceScope scope(c->device);
+  if (scope.err != hipSuccess) return set_error(SCTL_AMD_ERR_HIP, "hipSetDevice failed");
+  const int right = (c->rank + 1) % c->size, left = (c->rank + c->size - 1) % c->size;
+  std::vector<unsigned char> h((size_t)bytes), back((size_t)bytes);
+  for (int64_t i = 0; i < bytes; i++) h[(size_t)i] = (unsigned char)(c->rank * 31 + i * 7);
+  void *a = nullptr, *b = nullptr;
+  hipStream_t st = nullptr;
+  auto done = [&](int rc) { if (a) (void)hipFree(a); if (b) (void)hipFree(b); if (st) (void)hipStreamDestroy(st); return rc; };
+  if (hipMalloc(&a, (size_t)bytes) != hipSuccess || hipMalloc(&b, (size_t)bytes) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess)
+    return done(set_error(SCTL_AMD_ERR_HIP, "allocation failed"));
+  if (hipMemcpy(a, h.data(), (size_t)bytes, hipMemcpyHostToDevice) != hipSuccess || hipMemset(b, 0, (size_t)bytes) != hipSuccess) return done(set_error(SCTL_AMD_ERR_HIP, "copy failed"));
+  int rc = c->rccl.GroupStart();
+  if (rc == 0) rc = c->rccl.Send(a, (size_t)bytes, kRcclChar, right, c->nccl, st);
+  if (rc == 0) rc = c->rccl.Recv(b, (size_t)bytes, kRcclChar, left, c->nccl, st);
+  const int rc2 = c->rccl.GroupEnd();
+  if (rc == 0) rc = rc2;
+  if (rc != 0) return done(set_error(SCTL_AMD_ERR_HIP, std::string("RCCL send/recv failed: ") + (c->rccl.GetErrorString ? c->rccl.GetErrorString(rc) : "?")));
+  if (hipStreamSynchronize(st) != hipSuccess || hipMemcpy(back.data(), b, (size_t)bytes, hipMemcpyDeviceToHost) != hipSuccess) return done(set_error(SCTL_AMD_ERR_HIP, "synchronisation failed"));
+  for (int64_t i = 0; i < bytes; i++)
+    if (back[(size_t)i] != (unsigned char)(left * 31 + i * 7)) return done(set_error(SCTL_AMD_ERR_HIP, "RCCL delivered wrong bytes at offset " + std::to_string(i)));
+  return done(SCTL_AMD_OK);
 }
 
 int sctl_amd_comm_barrier(sctl_amd_comm* c) {

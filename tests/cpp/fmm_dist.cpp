@@ -41,6 +41,7 @@ int main(int argc, char** argv) {
     std::printf("rank %d host collectives ok\n", rank);
     return 0;
   }
+  if (comm.UsesRCCL()) CheckStatus(sctl_amd_comm_selftest(comm.Handle(), 1 << 16), "sctl_amd_comm_selftest");   // ring of sends over xGMI
   srand48(0);
   Vector<double> Xt(N * 3), Xd(N * 3), Nd(N * 3), Fd(N * 3), Xs(N * 3), Fs(N * 3);
   for (auto& a : Xt) a = drand48() - 0.5;

@@ -91,3 +91,27 @@ def test_rank_parallel_eval_direct_over_rccl(tmp_path, O):
         assert rc == 0, (r, o, e)
         assert "transport rccl" in o
     _check_slices(O, tmp_path, N, world)
+
+
+@pytest.mark.gpu
+def test_rccl_binding_on_one_gpu():
+    """The dlopen()ed RCCL entry points (ncclGetUniqueId, ncclCommInitRank with the id passed by value, grouped ncclSend / ncclRecv, destroy)
+    on a one-rank communicator: what the one-GPU box can check of the RCCL data path of sctl_amd/csrc/comm.hip."""
+    import ctypes as C
+    import sctl_amd
+    L = sctl_amd.lib()
+    L.sctl_amd_comm_create.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.sctl_amd_comm_selftest.argtypes = [C.c_void_p, C.c_int64]
+    L.sctl_amd_comm_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 4
+    L.sctl_amd_comm_destroy.argtypes = [C.c_void_p]
+    L.sctl_amd_comm_destroy.restype = None
+    h = C.c_void_p()
+    assert L.sctl_amd_comm_create(0, 1, None, 0, 0, 2, C.byref(h)) == 0, sctl_amd.last_error()      # flags = SCTL_AMD_COMM_FORCE_RCCL
+    transport = C.c_int(-1)
+    assert L.sctl_amd_comm_info(h, None, None, None, C.byref(transport)) == 0 and transport.value == 1
+    assert L.sctl_amd_comm_selftest(h, 1 << 20) == 0, sctl_amd.last_error()
+    L.sctl_amd_comm_destroy(h)
+    plain = C.c_void_p()
+    assert L.sctl_amd_comm_create(0, 1, None, 0, 0, 0, C.byref(plain)) == 0
+    assert L.sctl_amd_comm_selftest(plain, 64) == -2                                              # sockets-only communicator
+    L.sctl_amd_comm_destroy(plain)
