@@ -105,6 +105,33 @@ template <class uKernel> class GenericKernel : public uKernel {
     CheckStatus(rc, "sctl_amd_kernel_matrix_batch_host");
   }
 
+  // Many (target range x source range) direct sums in ONE device launch — the P2P / U-list shape in which PVFMM calls a kernel once
+  // per box pair (fmm-wrapper.txx:756-786); not in the reference's GenericKernel.  List l adds to targets [trg_off[l], +trg_cnt[l]) the
+  // potential of sources [src_off[l], +src_cnt[l]) (offsets and counts in points); target ranges must be identical or disjoint.
+  // v_trg follows Eval's rule: right size = accumulated into, otherwise resized and zeroed.
+  template <class Real, Integer digits = -1>
+  void EvalLists(Vector<Real>& v_trg, const Vector<Real>& r_trg, const Vector<Real>& r_src, const Vector<Real>& n_src, const Vector<Real>& v_src,
+                 const Vector<Long>& trg_off, const Vector<Long>& trg_cnt, const Vector<Long>& src_off, const Vector<Long>& src_cnt) const {
+    static_assert(sizeof(Long) == sizeof(int64_t), "Long must be 64 bits wide");
+    const Long Ns = r_src.Dim() / DIM, Nt = r_trg.Dim() / DIM, nl = trg_off.Dim();
+    SCTL_AMD_ASSERT(r_trg.Dim() == Nt * DIM);
+    SCTL_AMD_ASSERT(r_src.Dim() == Ns * DIM);
+    SCTL_AMD_ASSERT(v_src.Dim() == Ns * KDIM0);
+    SCTL_AMD_ASSERT(n_src.Dim() == Ns * N_DIM || !N_DIM);
+    SCTL_AMD_ASSERT(trg_cnt.Dim() == nl && src_off.Dim() == nl && src_cnt.Dim() == nl);
+    if (v_trg.Dim() != Nt * KDIM1) {
+      v_trg.ReInit(Nt * KDIM1);
+      v_trg.SetZero();
+    }
+    if (!nl) return;
+    RequireSupported();
+    auto i64 = [](const Vector<Long>& v) { return reinterpret_cast<const int64_t*>(&v[0]); };
+    const int rc = sctl_amd_eval_lists_host(DeviceKernelId(), RealTag<Real>::value, nl, i64(trg_off), i64(trg_cnt), i64(src_off), i64(src_cnt), Nt, Ns, r_trg.begin(),
+                                            r_src.begin(), N_DIM ? n_src.begin() : nullptr, v_src.begin(), v_trg.begin(), (int)digits, ctx_ptr,
+                                            (int)uKernel::CTX_BYTES, DeviceSet::Get()[0]);
+    CheckStatus(rc, "sctl_amd_eval_lists_host");
+  }
+
  private:
   static void RequireSupported() {
     if (!IsSupported()) {

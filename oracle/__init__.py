@@ -24,7 +24,7 @@ KERNELS = ["Laplace3D-FxU", "Laplace3D-DxU", "Laplace3D-FxdU", "Stokes3D-FxU", "
 def build(ref=True):
     subprocess.run(["make", "-s", "-C", _HERE, "oracle"], check=True)
     if ref and os.path.isdir("/root/reference/include/sctl"):
-        subprocess.run(["make", "-s", "-C", _HERE, "ref", "-j2"], check=True)
+        subprocess.run(["make", "-s", "-C", _HERE, "ref", "-j5"], check=True)
 
 
 def _ptr(a):

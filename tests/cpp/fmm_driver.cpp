@@ -114,6 +114,20 @@ int main(int argc, char** argv) {
   }
   int64_t pairs = 0, flops = 0;
   sctl_amd_counters(&pairs, &flops);
+  {  // list evaluation from the header surface: the targets in three ranges, every range against two source ranges that together
+     // hold all sources == one plain Eval (to summation order); counted after the totals printed below were taken
+    const Long a = N / 3, b = 2 * N / 3, h = N / 2;
+    Vector<Long> to(6), tc(6), so(6), sc(6);
+    const Long t0[3] = {0, a, b}, t1[3] = {a, b, N};
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 2; j++) { to[2 * i + j] = t0[i]; tc[2 * i + j] = t1[i] - t0[i]; so[2 * i + j] = j ? h : 0; sc[2 * i + j] = j ? N - h : h; }
+    Vector<Real> Ul, Ue;
+    kernel_sl.EvalLists<Real>(Ul, trg_coord, sl_coord, Vector<Real>(), sl_den, to, tc, so, sc);
+    kernel_sl.Eval<Real, true>(Ue, trg_coord, sl_coord, Vector<Real>(), sl_den);
+    Real dmax = 0, umax = 0;
+    for (Long i = 0; i < Ue.Dim(); i++) { dmax = std::max<Real>(dmax, std::fabs(Ul[i] - Ue[i])); umax = std::max<Real>(umax, std::fabs(Ue[i])); }
+    SCTL_AMD_ASSERT(Ul.Dim() == N * 3 && dmax <= 1e-13 * umax);
+  }
   std::cout << "pair interactions: " << pairs << "  SCTL-convention flops: " << flops << '\n';
   return 0;
 }

@@ -177,3 +177,22 @@ def test_hip_lists_equal_plain_eval_for_one_list(O):
     a = sctl_amd.eval_lists_host("Stokes3D-FxU", *one, xt, xs, None, f)
     b = sctl_amd.eval_host("Stokes3D-FxU", xt, xs, None, f)
     assert rel_l2(a, b) < 1e-14
+
+
+@pytest.mark.gpu
+def test_one_shot_device_entry(O):
+    """sctl_amd_eval_lists_device: device arrays, plan built and released inside the call, returns after the stream has finished."""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(3)
+    Nt, Ns = 900, 1200
+    xt, xs, f = rng.random(Nt * 3), rng.random(Ns * 3), rng.random(Ns) - 0.5
+    lists = [np.array(v, dtype=np.int64) for v in ([0, 0, 300, 700], [300, 300, 400, 200], [0, 600, 100, 0], [600, 600, 900, 1200])]
+    d = [torch.from_numpy(a).cuda() for a in (xt, xs, f)]
+    u = torch.zeros(Nt, dtype=torch.float64, device="cuda")
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = sctl_amd.lib().sctl_amd_eval_lists_device(0, 0, 4, p(lists[0]), p(lists[1]), p(lists[2]), p(lists[3]), Nt, Ns, C.c_void_p(d[0].data_ptr()), C.c_void_p(d[1].data_ptr()),
+                                                   None, C.c_void_p(d[2].data_ptr()), C.c_void_p(u.data_ptr()), -1, None, 0, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, sctl_amd.last_error()
+    ref = oracle_lists(O, "Laplace3D-FxU", lists, xt, xs, np.zeros(0), f)
+    assert rel_l2(u.cpu().numpy(), ref) < 1e-13
