@@ -116,8 +116,9 @@ int sctl_amd_eval_device(int kernel, int real, int64_t Nt, int64_t Ns, const voi
 /* The same for a SPATIALLY COMPACT slab of a larger target set: the Nt targets are a contiguous run of the Nt_whole
  * targets in space-filling-curve order, as a rank of a multi-GPU job holds them (fmm-wrapper.txx:504-512 partitions the
  * targets; here the partition follows a Morton curve so that a slab keeps the point density of the whole set).  The
- * result is the same as sctl_amd_eval_device's; Nt_whole only informs the choice between the exact kernel and the
- * tile-centred one, which depends on the target density and not on the count.  Nt_whole >= Nt. */
+ * result is the same as sctl_amd_eval_device's; Nt_whole informs the choice between the exact kernel and the tile-centred
+ * one, which depends on the target density and not on the count, and a proper slab (Nt_whole > Nt) is taken to be in curve order
+ * already, so the tile-centred path skips its own sort.  Nt_whole >= Nt. */
 int sctl_amd_eval_device_slab(int kernel, int real, int64_t Nt, int64_t Ns, int64_t Nt_whole, const void* r_trg, const void* r_src,
                               const void* n_src, const void* v_src, void* v_trg, int digits, const void* ctx, int ctx_bytes,
                               void* stream);

@@ -571,12 +571,16 @@ static int eval_device_entry(int kernel, int real, int64_t Nt, int64_t Ns, int64
   if (rc) return rc;
   if ((Ns > 0 && !v_src) || (Nt > 0 && !v_trg)) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "null density or potential array");
   if (nt_whole < Nt) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "a slab cannot hold more targets than the set it was cut from");
+  // A proper slab IS a run of the space-filling-curve order (the entry's contract): the tile-centred path then needs no sort, gather or
+  // scatter of its own.  (Targets in any other order are still evaluated correctly — only slowly: their clusters are large, so most
+  // sources take the exact near path.)
+  const bool slab_sorted = nt_whole > Nt;
   if (device_count_quiet() <= 0) return fail(SCTL_AMD_ERR_NO_DEVICE, "no HIP device: libsctl_amd has no CPU fallback");
   if (real == SCTL_AMD_F64)
     return eval_device_t<double>(*k, real, Nt, Ns, (const double*)r_trg, (const double*)r_src, (const double*)n_src, (const double*)v_src,
-                                 (double*)v_trg, digits, ctx, (hipStream_t)stream, nt_whole);
+                                 (double*)v_trg, digits, ctx, (hipStream_t)stream, nt_whole, slab_sorted);
   return eval_device_t<float>(*k, real, Nt, Ns, (const float*)r_trg, (const float*)r_src, (const float*)n_src, (const float*)v_src, (float*)v_trg,
-                              digits, ctx, (hipStream_t)stream, nt_whole);
+                              digits, ctx, (hipStream_t)stream, nt_whole, slab_sorted);
 }
 
 int sctl_amd_eval_device(int kernel, int real, int64_t Nt, int64_t Ns, const void* r_trg, const void* r_src, const void* n_src,

@@ -60,7 +60,7 @@ int sctl_amd_lists_create(int kernel, int real, int device, int64_t nlists, cons
   std::vector<Group> groups;
   std::vector<ListRange> ranges;
   ranges.reserve(order.size());
-  int64_t pairs = 0, trg_in_groups = 0;
+  int64_t pairs = 0;
   for (size_t i = 0; i < order.size(); i++) {
     const int64_t l = order[i];
     if (groups.empty() || groups.back().t0 != trg_off[l] || groups.back().nt != trg_cnt[l]) {
@@ -68,7 +68,6 @@ int sctl_amd_lists_create(int kernel, int real, int device, int64_t nlists, cons
         return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "the target ranges of lists " + std::to_string(order[i - 1]) + " and " + std::to_string(l) +
                                                         " overlap without being equal: target ranges must be identical or disjoint");
       groups.push_back(Group{trg_off[l], trg_cnt[l], (int64_t)ranges.size(), 0, 0});
-      trg_in_groups += trg_cnt[l];
     }
     ranges.push_back(ListRange{src_off[l], src_cnt[l]});
     groups.back().nranges++;
@@ -77,7 +76,6 @@ int sctl_amd_lists_create(int kernel, int real, int device, int64_t nlists, cons
   }
   for (const Group& g : groups)
     if (g.nranges > INT32_MAX) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "too many lists for one target range");
-  (void)trg_in_groups;
   // Eight shares, one per XCD (lists_kernel.hpp): contiguous runs of target ranges in the caller's order — a tree code lists its
   // boxes along a space-filling curve, so a run is a compact region whose boxes stream the same sources — each with 1/8 of the
   // pair count.  Inside a share: long items first (a short tail), coarsely — by the number of 4096-source chunks —, neighbours

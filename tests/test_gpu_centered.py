@@ -121,6 +121,12 @@ def test_compact_slab_uses_the_centred_path_and_matches(O):
         sel = rng.choice(n, 200, replace=False)
         ref = O.eval("Laplace3D-FxU", slab.cpu().numpy().reshape(n, 3)[sel].ravel().copy(), xs.cpu().numpy(), None, f.cpu().numpy())
         assert rel_l2(u[sel], ref) <= 1e-12
+    # a "slab" that is NOT in curve order (the hint's contract broken): still the right potential — every wave's cluster is then the whole
+    # slab, its sources are all "near" and take the exact path
+    shuffle = torch.from_numpy(rng.permutation(n)).cuda()
+    u_bad = sctl_amd.eval_device("Laplace3D-FxU", slab.view(-1, 3)[shuffle].contiguous().view(-1), xs[:3 * 65536].contiguous(), None, f[:65536].contiguous(), nt_whole=n_whole)
+    u_ok = sctl_amd.eval_device("Laplace3D-FxU", slab, xs[:3 * 65536].contiguous(), None, f[:65536].contiguous())
+    assert rel_l2(u_bad.cpu().numpy(), u_ok[shuffle].cpu().numpy()) <= 2e-14
     with pytest.raises(sctl_amd.api.SctlAmdError):
         sctl_amd.eval_device("Laplace3D-FxU", slab, xs, None, f, nt_whole=n - 1)         # a slab larger than its whole
 
