@@ -23,6 +23,7 @@
 #include <map>
 #include <string>
 #include <utility>
+#include <vector>
 
 #include "comm.hpp"
 #include "generic-kernel.hpp"
@@ -161,10 +162,18 @@ template <class Real, Integer DIM = 3> class ParticleFMM {
         CheckStatus(sctl_amd_op_set_targets(s2t.op, Nt, Xt.begin()), "sctl_amd_op_set_targets");
         s2t.trg_dirty = false;
       }
-      if (ranks) {   // collective: every rank comes through here for every S2T pair, in map order; coordinates are re-gathered on
-                     // every evaluation (a rank cannot know whether ANOTHER rank moved its sources)
-        CheckStatus(sctl_amd_op_set_sources_dist(s2t.op, comm_.Handle(), Ns, src_data.X.begin(), NorDim ? src_data.Xn.begin() : nullptr), "sctl_amd_op_set_sources_dist");
-        s2t.src_dirty = true;
+      if (ranks) {   // collective: every rank comes through here for every S2T pair, in map order
+        // coordinates are re-gathered only when SOME rank moved its sources since the last evaluation (one byte per rank decides)
+        const char mine = s2t.src_dirty ? 1 : 0;
+        std::vector<char> flags((size_t)comm_.Size(), 0);
+        std::vector<int64_t> sizes((size_t)comm_.Size(), 0);
+        CheckStatus(sctl_amd_comm_allgatherv_host(comm_.Handle(), &mine, 1, flags.data(), (int64_t)flags.size(), sizes.data()), "sctl_amd_comm_allgatherv_host");
+        bool any_dirty = false;
+        for (char fl : flags) any_dirty = any_dirty || fl;
+        if (any_dirty) {
+          CheckStatus(sctl_amd_op_set_sources_dist(s2t.op, comm_.Handle(), Ns, src_data.X.begin(), NorDim ? src_data.Xn.begin() : nullptr), "sctl_amd_op_set_sources_dist");
+          s2t.src_dirty = false;
+        }
         const int rc = sctl_amd_op_eval_dist(s2t.op, comm_.Handle(), Ns, src_data.F.begin(), U.begin(), 1, (int)digits_, s2t.ctx_bytes ? s2t.ctx.data() : nullptr, s2t.ctx_bytes);
         CheckStatus(rc, "sctl_amd_op_eval_dist");
         continue;

@@ -85,6 +85,16 @@ int main(int argc, char** argv) {
   fmm.Eval(U2, "Velocity");                    // a second collective evaluation on the same object: same bits
   for (Long i = 0; i < U.Dim(); i++) SCTL_AMD_ASSERT(U[i] == U2[i]);
   U.Write((out + ".r" + std::to_string(rank)).c_str());
+  // ONE rank moves its double-layer sources (here: the last rank negates its normals); every rank's next Eval must see it
+  if (rank == np - 1) {
+    Vector<double> nd = part(Nd, s0, s1, 3);
+    Vector<double> flipped(nd.Dim());
+    for (Long i = 0; i < nd.Dim(); i++) flipped[i] = -nd[i];
+    fmm.SetSrcCoord("DoubleLayer", part(Xd, s0, s1, 3), flipped);
+  }
+  Vector<double> U3;
+  fmm.Eval(U3, "Velocity");
+  U3.Write((out + ".moved.r" + std::to_string(rank)).c_str());
   comm.Barrier();
   return 0;
 }

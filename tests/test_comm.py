@@ -58,11 +58,16 @@ def _check_slices(O, tmp_path, N, world):
     g = Rand48(0)
     xt, xd, nd, fd, xs, fs = (g.drand48(N * 3) - 0.5 for _ in range(6))
     ref = (O.eval("Stokes3D-DxU", xt, xd, nd, fd) + O.eval("Stokes3D-FxU", xt, xs, None, fs)).reshape(N, 3)
+    # after the LAST rank flipped the normals of its double-layer sources (it owns the first slice: the shares run the other way round)
+    nd2 = nd.copy().reshape(N, 3)
+    nd2[:_cut(N, 1, world)] *= -1
+    ref2 = (O.eval("Stokes3D-DxU", xt, xd, nd2.ravel(), fd) + O.eval("Stokes3D-FxU", xt, xs, None, fs)).reshape(N, 3)
     for r in range(world):
-        u = _read_vector(str(tmp_path / "u") + ".r%d" % r)
         t0, t1 = _cut(N, r, world), _cut(N, r + 1, world)
-        assert u.size == (t1 - t0) * 3
-        assert rel_l2(u, ref[t0:t1]) <= 1e-12, (r, rel_l2(u, ref[t0:t1]))
+        for tag, want in ((".r%d" % r, ref), (".moved.r%d" % r, ref2)):
+            u = _read_vector(str(tmp_path / "u") + tag)
+            assert u.size == (t1 - t0) * 3
+            assert rel_l2(u, want[t0:t1]) <= 1e-12, (r, tag, rel_l2(u, want[t0:t1]))
 
 
 @pytest.mark.gpu
