@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
+#include <poll.h>
 #include <sys/socket.h>
 #include <unistd.h>
 
@@ -226,6 +227,8 @@ int sctl_amd_comm_create(int rank, int size, const char* master_addr, int master
       return set_error(SCTL_AMD_ERR_HIP, std::string("cannot listen on ") + master_addr + ":" + std::to_string(master_port));
     c->fd.assign((size_t)size, -1);
     for (int k = 1; k < size; k++) {
+      pollfd pf{c->listen_fd, POLLIN, 0};
+      if (::poll(&pf, 1, 300 * 1000) <= 0) return set_error(SCTL_AMD_ERR_HIP, "rendezvous: " + std::to_string(size - k) + " rank(s) did not connect within 5 minutes");
       const int f = ::accept(c->listen_fd, nullptr, nullptr);
       int32_t r = -1;
       if (f < 0 || !recv_all(f, &r, 4) || r < 1 || r >= size || c->fd[(size_t)r] >= 0) { if (f >= 0) ::close(f); return set_error(SCTL_AMD_ERR_HIP, "rendezvous: bad peer"); }
