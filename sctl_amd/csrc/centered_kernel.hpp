@@ -124,7 +124,20 @@ __global__ void __launch_bounds__(kWaveBlock) centered_kernel(const EvalArgs<R> 
   R* const farX = (R*)farXv;
 
   const int lane = threadIdx.x;
-  const int64_t tbase = (int64_t)blockIdx.x * (kWaveBlock * T);
+  // Which (target tile, source split) this workgroup takes.  Workgroups are dealt round-robin over the 8 XCDs in launch order
+  // (b = y * gridDim.x + x; blocks b, b + 8, ... share an XCD and its L2).  With the plain (x, y) = blockIdx every XCD sees every
+  // source split — 8 x the source data through the fabric —; when the splits divide by 8, XCD k instead owns the splits
+  // [k * gridDim.y / 8, (k + 1) * gridDim.y / 8) for ALL tiles: one split (2 MB at 2^20 sources / 16) stays in its 4 MB L2 while the
+  // tiles stream by.  Same work per XCD; the results do not depend on the mapping.
+  unsigned tile_idx = blockIdx.x, split_idx = blockIdx.y;
+#if !(defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_PLAIN_MAP))   // (the A/B build of tools/ab_xcd_map.sh)
+  if ((gridDim.y & 7u) == 0) {
+    const unsigned b = blockIdx.y * gridDim.x + blockIdx.x, xcd = b & 7u, j = b >> 3, per = gridDim.y >> 3;
+    tile_idx = j % gridDim.x;
+    split_idx = xcd * per + j / gridDim.x;
+  }
+#endif
+  const int64_t tbase = (int64_t)tile_idx * (kWaveBlock * T);
   const typename Ker::template Consts<R> K(nullptr);
 
   // ---- targets of this lane, cluster centre (bounding-box midpoint) and radius --------------------------------
@@ -162,7 +175,7 @@ __global__ void __launch_bounds__(kWaveBlock) centered_kernel(const EvalArgs<R> 
 #pragma unroll
   for (int j = 0; j < T; j++) acc[j][0] = 0;
 
-  const int64_t s_begin = (int64_t)blockIdx.y * a.chunk;
+  const int64_t s_begin = (int64_t)split_idx * a.chunk;
   const int64_t s_end = (s_begin + a.chunk < a.Ns) ? s_begin + a.chunk : a.Ns;
   const int64_t len = (s_end > s_begin) ? s_end - s_begin : 0;
   const int ntile = (int)((len + kWaveTile - 1) / kWaveTile);
@@ -284,7 +297,7 @@ __global__ void __launch_bounds__(kWaveBlock) centered_kernel(const EvalArgs<R> 
     const int64_t t = tbase + j * kWaveBlock + lane;
     if (t < a.Nt) {
       if (gridDim.y == 1) a.v_trg[t] += acc[j][0] * a.scale;
-      else a.partial[(int64_t)blockIdx.y * a.Nt + t] = acc[j][0];
+      else a.partial[(int64_t)split_idx * a.Nt + t] = acc[j][0];
     }
   }
 }
