@@ -23,7 +23,7 @@ constexpr int kListTile = 64;    // sources per LDS tile
 
 struct ListItem {       // one wave
   int64_t t0;           // first target (point index)
-  int32_t nt;           // targets of this item: 65 .. 128 (two per lane) or 1 .. 64 (one per lane)
+  int32_t nt;           // targets of this item: 65 .. 128 (two per lane), 33 .. 64 (one per lane) or 1 .. 32 (replicas)
   int32_t nranges;      // source ranges of the target box
   int64_t first_range;  // index of the first one in the range array
 };
@@ -48,8 +48,14 @@ template <class R> struct ListArgs {
 // One work item with T targets per lane.  Each LDS tile is first evaluated WITHOUT the r = 0 mask into per-tile sums; a coincident
 // pair (a box acting on itself: 1 of its ~27 lists) poisons them with inf/NaN, which one compare per tile detects, and the wave
 // re-runs that tile masked — the same speculation as eval_kernel.hpp, worth ~9 % on the Laplace kernel.
-template <class Ker, class R, int MODE, int T, class KC, class V>
+//
+// SPLIT (T = 1, at most 32 targets): the wave would idle most of its lanes, so it is cut into 64/P REPLICAS of P lanes (P = the
+// power of two >= the target count, at least 8): every replica holds all the targets and takes every (64/P)-th source of a tile; the
+// replicas' sums are added with a butterfly of lane shuffles at the end (a fixed order: still deterministic).  An 8-point leaf then
+// costs an eighth of a wave pass per source instead of a whole one.
+template <class Ker, class R, int MODE, int T, bool SPLIT, class KC, class V>
 __device__ __forceinline__ void lists_item(const ListArgs<R>& a, const ListItem& it, V* tile, const KC& K) {
+  static_assert(!SPLIT || T == 1, "replicas are for small one-target-per-lane items");
   constexpr int K0 = Ker::K0, K1 = Ker::K1, ND = Ker::ND, NREC = Ker::NREC;
   constexpr int VN = VecOf<R>::N;
   constexpr int NV = (NREC + VN - 1) / VN;
@@ -57,10 +63,14 @@ __device__ __forceinline__ void lists_item(const ListArgs<R>& a, const ListItem&
   const int lane = threadIdx.x;
   const ListRange* const rg = a.ranges + it.first_range;
 
+  int P = kListWave;                       // lanes per replica
+  if (SPLIT) { P = 8; while (P < it.nt) P <<= 1; }
+  const int nrep = kListWave / P, rep = lane / P;
+
   R xt[T][3], acc[T][K1];
 #pragma unroll
   for (int j = 0; j < T; j++) {
-    int tl = j * kListWave + lane;
+    int tl = SPLIT ? (lane & (P - 1)) : (j * kListWave + lane);
     if (tl >= it.nt) tl = it.nt - 1;      // idle lanes repeat the last target; never stored
     const int64_t t = it.t0 + tl;
 #pragma unroll
@@ -142,7 +152,13 @@ __device__ __forceinline__ void lists_item(const ListArgs<R>& a, const ListItem&
           else Ker::template pair<R, MODE, MASKED>(tacc[j], d, rec, a.ctx, K);
         }
       };
-      if (ns_cur == kListTile) {
+      if (SPLIT) {                         // replica `rep` takes sources rep, rep + nrep, ... of the tile
+        const int cnt = (ns_cur + nrep - 1) / nrep;   // wave-uniform trip count; the tail of a short tile is predicated
+        for (int i = 0; i < cnt; i++) {
+          const int s = i * nrep + rep;
+          if (s < ns_cur) one_source(s);
+        }
+      } else if (ns_cur == kListTile) {
 #pragma unroll UnrollOf<T, Ker::K1>::value
         for (int s = 0; s < kListTile; s++) one_source(s);
       } else {
@@ -176,10 +192,15 @@ __device__ __forceinline__ void lists_item(const ListArgs<R>& a, const ListItem&
       for (int k = 0; k < K1; k++) acc[j][k] += tacc[j][k];
   }
 
+  if (SPLIT) {                             // add the replicas' sums: lanes l, l ^ P, l ^ 2P, ... hold the same target
+    for (int off = P; off < kListWave; off <<= 1)
+#pragma unroll
+      for (int k = 0; k < K1; k++) acc[0][k] += __shfl_xor(acc[0][k], off);
+  }
 #pragma unroll
   for (int j = 0; j < T; j++) {
-    const int tl = j * kListWave + lane;
-    if (tl < it.nt) {
+    const int tl = SPLIT ? (lane & (P - 1)) : (j * kListWave + lane);
+    if (tl < it.nt && (!SPLIT || rep == 0)) {
       const int64_t t = it.t0 + tl;
 #pragma unroll
       for (int k = 0; k < K1; k++) a.v_trg[t * K1 + k] += acc[j][k] * a.scale;   // generic-kernel.txx:184
@@ -187,8 +208,8 @@ __device__ __forceinline__ void lists_item(const ListArgs<R>& a, const ListItem&
   }
 }
 
-// An item with more than 64 targets runs two targets per lane (half the LDS reads per pair), a smaller one a single target per lane
-// (no idle second slot): the host cuts every target range into 128-target items plus, for a remainder of at most 64, one such item.
+// An item with more than 64 targets runs two targets per lane (half the LDS reads per pair), one with 33..64 a single target per
+// lane (no idle second slot), a smaller one replicas of 8..32 lanes (lists_item, SPLIT); lists.hip cuts the target ranges accordingly.
 template <class Ker, class R, int MODE>
 __global__ void __launch_bounds__(kListWave) lists_kernel(const ListArgs<R> a) {
   using V = typename VecOf<R>::type;
@@ -205,8 +226,9 @@ __global__ void __launch_bounds__(kListWave) lists_kernel(const ListArgs<R> a) {
   const int xcd = blockIdx.x % 8, j = blockIdx.x / 8;
   if (j >= a.xcd_first[xcd + 1] - a.xcd_first[xcd]) return;
   const ListItem it = a.items[a.xcd_first[xcd] + j];
-  if (it.nt > kListWave) lists_item<Ker, R, MODE, 2>(a, it, tile, K);
-  else lists_item<Ker, R, MODE, 1>(a, it, tile, K);
+  if (it.nt > kListWave) lists_item<Ker, R, MODE, 2, false>(a, it, tile, K);
+  else if (it.nt > kListWave / 2) lists_item<Ker, R, MODE, 1, false>(a, it, tile, K);
+  else lists_item<Ker, R, MODE, 1, true>(a, it, tile, K);
 }
 
 }  // namespace sctl_amd

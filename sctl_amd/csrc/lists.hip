@@ -94,9 +94,11 @@ int sctl_amd_lists_create(int kernel, int real, int device, int64_t nlists, cons
       std::stable_sort(gorder.begin(), gorder.end(), [&](size_t a, size_t b) { return (groups[a].nsrc >> 12) > (groups[b].nsrc >> 12); });
       for (size_t gi : gorder) {
         const Group& g = groups[gi];
-        // 128-target items (two targets per lane: half the LDS reads per pair); a remainder of at most 64 gets a one-target-per-lane item
+        // 128-target items (two targets per lane: half the LDS reads per pair); the remainder: more than 96 -> one more such item,
+        // 65..96 -> a one-target-per-lane item of 64 plus a small one, up to 64 -> one item (up to 32: run as lane replicas)
         for (int64_t t = 0; t < g.nt;) {
-          const int64_t left = g.nt - t, n = left > kListWave ? std::min<int64_t>(left, 2 * kListWave) : left;
+          const int64_t left = g.nt - t;
+          const int64_t n = left > 96 ? std::min<int64_t>(left, 2 * kListWave) : (left > kListWave ? kListWave : left);
           items.push_back(ListItem{g.t0 + t, (int32_t)n, (int32_t)g.nranges, g.first_range});
           t += n;
         }
