@@ -4,7 +4,9 @@
 // libsctl_amd.so gets) the SECOND allocation of a block the pool had just handed out and taken back returned memory
 // through which a kernel's partial sums were lost — ParticleFMM::Eval called twice on one object gave a wrong second
 // result in about half of the runs at N = 3000 and in every run at N = 5000, for every placement of stream
-// synchronisations around the pool calls, and never with plain hipMalloc (the driver is tests/cpp/fmm_repeat.cpp, run by tests/test_cpp_host.py).  Python callers did
+// synchronisations around the pool calls, and never with plain hipMalloc (the driver is tests/cpp/fmm_repeat.cpp, run by tests/test_cpp_host.py).  tools/ubench/pool_reuse.hip
+// reproduces it stand-alone: 21 of 36000 evaluations read one or two of 16 freshly written slabs back as zeros with the pool, none of
+// 36000 with hipMalloc (profiles/r02_platform_probes.txt).  Python callers did
 // not see it because PyTorch brings the ROCm 7.0 runtime into the process.
 //
 // Instead: one grow-only hipMalloc'd block per (device, stream).  A call acquires the block of its stream once and
