@@ -19,6 +19,7 @@
 #ifndef SCTL_AMD_GENERIC_KERNEL_HPP_
 #define SCTL_AMD_GENERIC_KERNEL_HPP_
 
+#include <atomic>
 #include <string>
 
 #include "common.hpp"
@@ -48,9 +49,13 @@ template <class uKernel> class GenericKernel : public uKernel {
 
   // Device kernel id of this functor, or a negative value when libsctl_amd.so does not implement it.
   static int DeviceKernelId() {
-    static int id = -1;       // only a hit is cached: a plugin may register this functor after the first query
-    if (id < 0) id = sctl_amd_kernel_id(uKernel::Name().c_str());
-    return id;
+    static std::atomic<int> id(-1);   // only a hit is cached: a plugin may register this functor after the first query
+    int v = id.load(std::memory_order_relaxed);
+    if (v < 0) {
+      v = sctl_amd_kernel_id(uKernel::Name().c_str());
+      if (v >= 0) id.store(v, std::memory_order_relaxed);
+    }
+    return v;
   }
   static bool IsSupported() { return DeviceKernelId() >= 0; }
 
