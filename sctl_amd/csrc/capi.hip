@@ -281,13 +281,14 @@ struct StreamGuard {
   ~StreamGuard() { if (s) { workspace_forget(s); (void)hipStreamDestroy(s); } }
 };
 
-// Pinned (hipHostMalloc) staging memory for every host<->device transfer of the host-pointer entry points.
-// Why not hipMemcpyAsync straight from the caller's pageable arrays: callers reuse their arrays (SCTL keeps one density
-// vector and rewrites it every solver iteration), and with ROCm 7.2 on this platform an H2D copy from a pageable buffer
-// whose CONTENTS changed since the previous copy from the SAME address delivered the old contents about once per
-// thousand transfers (tools/ubench/h2d_reuse.hip stresses this; in the library: 3-4 of 3000 with one reused host buffer, 0 of 3000 with alternating buffers,
-// with or without SDMA, with hipMemcpy as well as hipMemcpyAsync).  A CPU memcpy into pinned memory plus a DMA from
-// there costs ~1.5 % at 2^20 points and removes the hazard.
+// Pinned (hipHostMalloc) staging memory for every host<->device transfer of the host-pointer entry points: the caller's pageable
+// arrays are copied into a pinned slice by the CPU and DMA'd from there, so the copy is asynchronous to the host and never depends on
+// how the runtime stages pageable memory.  History: round 1 introduced this after seeing the OLD contents of a reused, rewritten host
+// array arrive on the device about once per thousand transfers, and blamed the H2D copy.  Round 2 could not reproduce that — neither
+// stand-alone (tools/ubench/h2d_reuse.hip) nor inside the library with the staging compiled out (tools/h2d_in_library.py: 0 wrong
+// results in 4000 iterations x 2 runtimes, profiles/r02_platform_probes.txt) — while the memory-pool fault that was removed at the
+// same time IS reproducible (workspace.hpp): the stale results were most likely that fault.  The staging stays (its cost, one CPU
+// memcpy, ~1.5 % at 2^20 points, is what the runtime's own pageable path pays too).
 struct PinnedBuf {
   char* p = nullptr;
   size_t cap = 0, used = 0;
@@ -316,8 +317,13 @@ inline size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
 hipError_t upload(void* dst, const void* src, size_t bytes, PinnedBuf& stage, hipStream_t st) {
   if (!bytes) return hipSuccess;
   char* q = stage.take(bytes);
+#if defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_NO_STAGING)   // A/B build of tools/h2d_in_library.py: copy straight from the caller's pageable array
+  (void)q;
+  return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+#else
   std::memcpy(q, src, bytes);
   return hipMemcpyAsync(dst, q, bytes, hipMemcpyHostToDevice, st);
+#endif
 }
 
 // grow-only device buffer and the per-(thread, device) cache of the one-shot host entry

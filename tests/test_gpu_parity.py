@@ -224,9 +224,8 @@ def test_device_resident_operator_handle(O):
 
 def test_reused_host_buffers_are_always_re_read(O):
     """Callers rewrite their coordinate / density arrays in place between evaluations (SCTL keeps one density vector per
-    source type).  Every host entry must deliver the NEW contents: a plain hipMemcpyAsync from a reused pageable buffer
-    returned stale data about once per thousand transfers on this platform, which is why the library stages through pinned
-    memory (capi.hip: PinnedBuf)."""
+    source type).  Every host entry must deliver the NEW contents, however the library moves them (capi.hip: PinnedBuf; round 1 saw
+    stale contents here about once per thousand transfers — most likely the memory-pool fault of workspace.hpp)."""
     name = "Stokes3D-DxU"
     info = sctl_amd.kernel_info(name)
     rng = np.random.default_rng(23)
