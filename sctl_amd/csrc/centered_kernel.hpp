@@ -68,6 +68,20 @@ constexpr int kWaveBlock = 64;   // lanes per workgroup of the centred kernel
 constexpr int kWaveTile = 64;    // sources per LDS tile
 constexpr int kNearCap = 128;    // capacity of the per-wave list of pending near sources
 
+// fp32 with two targets per lane: the two targets' far pairs as ONE stream of packed instructions.  gfx950 issues v_pk_fma_f32 (two
+// FMAs per lane) at the cost of one fp64 FMA, where two v_fma_f32 cost 1.3 (tools/ubench/valu_rates: 2.96 vs 2 x 1.93 cycles per
+// instruction per SIMD at 4 waves), and the compiler only packs the final accumulate by itself.  The target-side quantities live as
+// {target 0, target 1} register pairs for the whole kernel; a source value is broadcast to both halves by the instruction's op_sel.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int MODE> __device__ __forceinline__ f32x2 rsqrt_pair(f32x2 r2) {
+  f32x2 y = {__builtin_amdgcn_rsqf(r2[0]), __builtin_amdgcn_rsqf(r2[1])};
+  if (MODE >= 1) {   // more than 7 digits asked of fp32: the unnormalised Newton step, 2/r (matches rsqrt_newton2; acc_factor carries the 2)
+    const f32x2 a = r2 * y;
+    y = y * (f32x2{3.0f, 3.0f} - a * y);
+  }
+  return y;
+}
+
 // What a kernel needs to run on the centred path (scalar potentials, K1 = 1): besides {x', y', z', |x_s'|^2} a far source
 // carries XW more reals, written by put_extra / put_null and read once per source by load_extra; far_pair is the pair
 // evaluation from the centred quantities.  Near sources go through the kernel's own exact pair (Ker::pack / Ker::pair).
@@ -81,6 +95,21 @@ template <class R> struct CenteredFxU {      // u += f / r
   template <int MODE> static __device__ __forceinline__ void far_pair(R& acc, const R (&m2x)[3], R tt, const R (&b)[4], const Extra& e, const RsqConst<R>& K) {
     const R r2 = fma_(m2x[0], b[0], fma_(m2x[1], b[1], fma_(m2x[2], b[2], tt + b[3])));
     acc = fma_(e.f, (MODE == 1) ? rsqrt_newton2<false>(r2, K) : rsqrt_masked<MODE, false>(r2, K), acc);   // MODE 1: 2/r, as Ker::pair (acc_factor)
+  }
+  // all T targets of the lane against one far source
+  template <int MODE, int T> static __device__ __forceinline__ void far_pairs(R (&acc)[T], const R (&m2x)[T][3], const R (&tt)[T], const R (&b)[4], const Extra& e,
+                                                                                const RsqConst<R>& K) {
+    if constexpr (std::is_same<R, float>::value && T == 2) {
+      f32x2 r2 = f32x2{tt[0], tt[1]} + f32x2{b[3], b[3]};
+      r2 = f32x2{m2x[0][2], m2x[1][2]} * f32x2{b[2], b[2]} + r2;
+      r2 = f32x2{m2x[0][1], m2x[1][1]} * f32x2{b[1], b[1]} + r2;
+      r2 = f32x2{m2x[0][0], m2x[1][0]} * f32x2{b[0], b[0]} + r2;
+      const f32x2 a = f32x2{acc[0], acc[1]} + f32x2{e.f, e.f} * rsqrt_pair<MODE>(r2);
+      acc[0] = a[0]; acc[1] = a[1];
+    } else {
+#pragma unroll
+      for (int j = 0; j < T; j++) far_pair<MODE>(acc[j], m2x[j], tt[j], b, e, K);
+    }
   }
 };
 template <class R> struct CenteredDxU {      // u += ((x_t - x_s).n f) / r^3, with (x_t - x_s).n f = x_t'.nf - x_s'.nf
@@ -102,6 +131,25 @@ template <class R> struct CenteredDxU {      // u += ((x_t - x_s).n f) / r^3, wi
     const R y = (MODE == 1) ? rsqrt_newton2<false>(r2, K) : rsqrt_masked<MODE, false>(r2, K);                // MODE 1: 2/r, as Ker::pair (acc_factor)
     const R dn = fma_(m2x[0], e.g[0], fma_(m2x[1], e.g[1], fma_(m2x[2], e.g[2], e.g[3])));
     acc = fma_(dn, y * y * y, acc);
+  }
+  template <int MODE, int T> static __device__ __forceinline__ void far_pairs(R (&acc)[T], const R (&m2x)[T][3], const R (&tt)[T], const R (&b)[4], const Extra& e,
+                                                                                const RsqConst<R>& K) {
+    if constexpr (std::is_same<R, float>::value && T == 2) {
+      const f32x2 mx = {m2x[0][0], m2x[1][0]}, my = {m2x[0][1], m2x[1][1]}, mz = {m2x[0][2], m2x[1][2]};
+      f32x2 r2 = f32x2{tt[0], tt[1]} + f32x2{b[3], b[3]};
+      r2 = mz * f32x2{b[2], b[2]} + r2;
+      r2 = my * f32x2{b[1], b[1]} + r2;
+      r2 = mx * f32x2{b[0], b[0]} + r2;
+      const f32x2 y = rsqrt_pair<MODE>(r2);
+      f32x2 dn = mz * f32x2{e.g[2], e.g[2]} + f32x2{e.g[3], e.g[3]};
+      dn = my * f32x2{e.g[1], e.g[1]} + dn;
+      dn = mx * f32x2{e.g[0], e.g[0]} + dn;
+      const f32x2 a = f32x2{acc[0], acc[1]} + dn * (y * y * y);
+      acc[0] = a[0]; acc[1] = a[1];
+    } else {
+#pragma unroll
+      for (int j = 0; j < T; j++) far_pair<MODE>(acc[j], m2x[j], tt[j], b, e, K);
+    }
   }
 };
 
@@ -282,8 +330,7 @@ __global__ void __launch_bounds__(kWaveBlock) centered_kernel(const EvalArgs<R> 
         R b[4];
         Rec4<R>::get(farB + (s + u) * NW, b);
         const typename CP::Extra e = CP::load_extra(farX, s + u);
-#pragma unroll
-        for (int j = 0; j < T; j++) CP::template far_pair<MODE>(tacc[j], m2x[j], tt[j], b, e, K.rsq);
+        CP::template far_pairs<MODE, T>(tacc, m2x, tt, b, e, K.rsq);
       }
     }
 #pragma unroll
