@@ -42,6 +42,17 @@ def cpu_impl():
     return oracle.reference() or oracle.restatement()
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(kernel, N, dtype, budget_s=12.0):
     """The reference's own OpenMP + Vec<> path (oracle/_ref, kind "reference") — or the CPU restatement ("port") when the
     compiled reference is not usable on this host — timed on a bounded target subset against ALL sources."""
@@ -67,7 +78,7 @@ def cpu_baseline(kernel, N, dtype, budget_s=12.0):
     nt -= nt % 64
     secs = run(nt)
     return {"value": nt * N / secs, "unit": "pair-interactions/s", "cores": impl.num_threads(), "kind": impl.kind,
-            "isa": getattr(impl, "isa", "x86-64-v3"),
+            "isa": getattr(impl, "isa", "x86-64-v3"), "cpu": cpu_model(),
             "sample": "%d targets x %d sources (all sources, target subset; work is linear in targets), %.1f s, %s" % (nt, N, secs, kernel)}
 
 
