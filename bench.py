@@ -38,7 +38,9 @@ PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}   # vector FMA peaks, BASELINE.md §3 
 
 
 def cpu_impl():
-    """The CPU side of the `cpu_baseline` legs — the ONLY place bench.py touches oracle/ (a reported comparator, never the thing measured):
+    """(No OMP_PROC_BIND: with "close" the reference ran 38 % SLOWER on the GPU box's 128-thread host — 3.2e10 against 5.2e10 pairs/s — so
+    the threads are left to the OS, which is the better number for the CPU side.)
+    The CPU side of the `cpu_baseline` legs — the ONLY place bench.py touches oracle/ (a reported comparator, never the thing measured):
     the reference's own OpenMP + Vec<> path compiled from its headers (oracle/_ref, kind "reference"), else the CPU restatement ("port")."""
     import oracle
     return oracle.reference() or oracle.restatement()
