@@ -18,9 +18,7 @@ import os
 import sys
 import time
 
-os.environ.setdefault("OMP_PROC_BIND", "close")   # for the cpu_baseline leg; read when the OpenMP runtime first loads
-
-import numpy as np  # noqa: E402
+import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
