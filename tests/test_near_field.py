@@ -198,6 +198,11 @@ def test_boundary_integral_near_field_end_to_end(tmp_path, case):
     u, un = _read_vector(out), _read_vector(out + ".near")
     assert rel_l2(un, gold(case, "u_near")) < 1e-12, rel_l2(un, gold(case, "u_near"))
     assert rel_l2(u, gold(case, "u_total")) < 1e-10, rel_l2(u, gold(case, "u_total"))     # the reference's far field ran at tol 1e-10
+    if case["key"] in ("c5", "t1"):      # the same through DeviceSet with three slabs (one GPU listed three times): far + near partitioned by target slab
+        p = subprocess.run(args, capture_output=True, text=True, timeout=300, env=dict(os.environ, SCTL_AMD_DEVICES="0,0,0"))
+        assert p.returncode == 0, p.stderr
+        u3 = _read_vector(out)
+        assert rel_l2(u3, u) < 1e-14 and rel_l2(u3, gold(case, "u_total")) < 1e-10
 
 
 @pytest.mark.gpu
