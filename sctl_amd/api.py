@@ -149,7 +149,21 @@ def load_plugin(path):
     return [lib().sctl_amd_kernel_name(i).decode() for i in range(n0, n0 + rc)]
 
 
+_INFO_CACHE = {}
+
+
 def kernel_info(name):
+    """Shape table of a kernel (by Name() or id).  Cached: a kernel's entry never changes once registered, and the evaluation wrappers
+    ask for it on every call (three ctypes round trips otherwise — visible in the step time of 2^14-point problems)."""
+    hit = _INFO_CACHE.get(name)
+    if hit is not None:
+        return hit
+    info = _kernel_info_uncached(name)
+    _INFO_CACHE[name] = _INFO_CACHE[info["id"]] = _INFO_CACHE[info["name"]] = info
+    return info
+
+
+def _kernel_info_uncached(name):
     k = kernel_id(name)
     v = [C.c_int() for _ in range(4)]
     sc, cb = C.c_double(), C.c_int()

@@ -150,7 +150,11 @@ struct Plan {
 Plan make_plan(const KernelEntry& k, int real, int64_t Nt, int64_t Ns) {
   // workgroups wanted: 8 per CU (32 waves) — measured +4 % over 4 per CU at Nt = 2^17, Ns = 2^20 and on the Stokeslet at
   // 2^18 — except for tiny problems, which are launch-bound and lose time to the extra partial sums
+#if defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_SMALL_WANT)   // A/B builds: workgroups per CU for small problems
+  const int64_t want = (int64_t)cu_count() * ((double)Nt * (double)Ns < 2147483648.0 ? SCTL_AMD_EXP_SMALL_WANT : 8);
+#else
   const int64_t want = (int64_t)cu_count() * ((double)Nt * (double)Ns < 2147483648.0 ? 4 : 8);
+#endif
   Plan p{};
   // Two targets per lane halve the LDS reads per pair and double the independent chains: 5-7 % faster than one target
   // per lane from Nt = 2^16 up on every kernel (Stokeslet 2^18: 56.2 vs 59.7 ms; traction kernel 72.5 vs 77.9 ms), with
