@@ -440,8 +440,9 @@ def main():
             line["at_reference_callers_accuracy"] = {"digits": 10, "ms_per_step": ms10, "value": pairs_per_step / (ms10 * 1e-3),
                                                      "frac": pairs_per_step * fpp / (ms10 * 1e-3) / 1e12 / peak,
                                                      "rel_l2_vs_full_precision": rel10,
-                                                     "per_pair_error_bound": "one Newton step from the v_rsq_f64 seed (relative error e <= 2^-24.2): 1/r is off by at most "
-                                                                             "3/8 e^2 <= 2^-49.8 = 1.0e-15 relative, for every digits in 8..14; 1e-12 rel-L2 needs nothing finer"}
+                                                     "per_pair_error_bound": "one Newton step from the v_rsq_f64 seed (relative error d <= 2^-24.18, measured): 1/r is low by "
+                                                                             "3/2 d^2 <= 4.3e-15 relative (rms 3.5e-16; profiles/r02_rsq_refine_accuracy.txt), for every digits in "
+                                                                             "8..14; the default mode measures 1.25 ulp, the reference's own default 2.5 ulp"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(kernel, N, dtype)

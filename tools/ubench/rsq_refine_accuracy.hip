@@ -1,0 +1,61 @@
+// Measured accuracy of the library's three reciprocal-square-root forms (include/sctl_amd/device/ukernels.hpp) against long double:
+//   MODE 0: the v_rsq_f64 seed;  MODE 1: the unnormalised Newton step 2/r = y0 (3 - x y0^2), halved here;  MODE 2: the Halley step.
+// With d = the seed's relative error, Newton leaves -3/2 d^2 (always too small) and Halley 5/2 d^3 plus rounding.
+// 2^27 arguments: a uniform grid over [1, 4) (both exponent parities) with random low mantissa bits, and a wide-exponent sample.
+// Build: hipcc -O3 --offload-arch=gfx950 -I../../include -o rsq_refine_accuracy rsq_refine_accuracy.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+#include <random>
+#include "sctl_amd/device/ukernels.hpp"
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+using namespace sctl_amd;
+
+__global__ void k(const double* x, double* y0, double* y1, double* y2, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const RsqConst<double> K;
+  y0[i] = rsqrt_masked<0, false>(x[i], K);
+  y1[i] = 0.5 * rsqrt_newton2<false>(x[i], K);
+  y2[i] = rsqrt_masked<2, false>(x[i], K);
+}
+
+int main() {
+  CHECK(hipSetDevice(0));
+  const int n = 1 << 22, rounds = 32;
+  std::vector<double> x(n), h0(n), h1(n), h2(n);
+  double *dx, *d0, *d1, *d2;
+  CHECK(hipMalloc(&dx, n * 8)); CHECK(hipMalloc(&d0, n * 8)); CHECK(hipMalloc(&d1, n * 8)); CHECK(hipMalloc(&d2, n * 8));
+  std::mt19937_64 g(7);
+  std::uniform_real_distribution<double> U(0.0, 1.0), E(-600, 600);
+  double m0 = 0, m1 = 0, m2 = 0, s0 = 0, s1 = 0, s2 = 0, lo1 = 0, hi1 = 0, bias1 = 0;
+  long long cnt = 0;
+  for (int r = 0; r < rounds; r++) {
+    for (int i = 0; i < n; i++) {
+      const double cell = 3.0 / ((double)n * (rounds - 4));
+      if (r < rounds - 4) x[i] = 1.0 + ((double)r * n + i + U(g)) * cell;                 // grid over [1, 4), random position inside the cell
+      else x[i] = (1.0 + 3.0 * U(g)) * std::pow(2.0, std::floor(E(g)));                    // wide exponent range
+    }
+    CHECK(hipMemcpy(dx, x.data(), n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k, dim3(n / 256), dim3(256), 0, 0, dx, d0, d1, d2, n);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipMemcpy(h0.data(), d0, n * 8, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(h1.data(), d1, n * 8, hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(h2.data(), d2, n * 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) {
+      const long double ex = 1.0L / sqrtl((long double)x[i]);
+      const double e0 = (double)((h0[i] - ex) / ex), e1 = (double)((h1[i] - ex) / ex), e2 = (double)((h2[i] - ex) / ex);
+      m0 = fmax(m0, fabs(e0)); m1 = fmax(m1, fabs(e1)); m2 = fmax(m2, fabs(e2));
+      s0 += e0 * e0; s1 += e1 * e1; s2 += e2 * e2; bias1 += e1;
+      lo1 = fmin(lo1, e1); hi1 = fmax(hi1, e1);
+      cnt++;
+    }
+  }
+  printf("%lld arguments\n", cnt);
+  printf("MODE 0 seed  (v_rsq_f64):        max rel err %.3e (2^%.2f), rms %.3e\n", m0, log2(m0), sqrt(s0 / cnt));
+  printf("MODE 1 Newton (unnormalised):    max rel err %.3e (2^%.2f), rms %.3e, mean %.3e, range [%.3e, %.3e]; 3/2 d_max^2 = %.3e\n", m1, log2(m1), sqrt(s1 / cnt),
+         bias1 / cnt, lo1, hi1, 1.5 * m0 * m0);
+  printf("MODE 2 Halley:                   max rel err %.3e (2^%.2f = %.2f ulp), rms %.3e\n", m2, log2(m2), m2 / 1.1102230246251565e-16, sqrt(s2 / cnt));
+  return 0;
+}
