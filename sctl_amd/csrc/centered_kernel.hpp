@@ -81,17 +81,40 @@ template <int MODE> __device__ __forceinline__ f32x2 rsqrt_pair(f32x2 r2) {
   }
   return y;
 }
+// {t0, t1} + the HIGH half of the register pair `zA` in both lanes, as one v_pk_add_f32.  Written out because the compiler, which finds the
+// op_sel broadcast for the packed FMAs by itself, copies the high half into a fresh register first for this add (one v_mov_b32 per far
+// source = 10 % of the fp32 far loop's issue cycles).  `zA` is the upper half {z', |x_s'|^2} of the record's ds_read_b128.
+__device__ __forceinline__ f32x2 pk_add_hi(f32x2 t, f32x2 zA) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(t), "v"(zA));
+  return r;
+}
+// m * (low half of g) + (high half of g) in both lanes: the first step of a dot product whose constant term sits next to its last coefficient
+__device__ __forceinline__ f32x2 pk_fma_lo_hi(f32x2 m, f32x2 g) {
+  f32x2 r;
+  asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(m), "v"(g));
+  return r;
+}
 
 // What a kernel needs to run on the centred path (scalar potentials, K1 = 1): besides {x', y', z', |x_s'|^2} a far source
 // carries XW more reals, written by put_extra / put_null and read once per source by load_extra; far_pair is the pair
 // evaluation from the centred quantities.  Near sources go through the kernel's own exact pair (Ker::pack / Ker::pair).
 template <class R> struct CenteredFxU {      // u += f / r
   using Ker = Laplace3D_FxU;
-  static constexpr int XW = 1;
-  struct Extra { R f; };
-  static __device__ __forceinline__ void put_extra(R* base, int q, const R (&)[3], const R*, const R* f) { base[q] = f[0]; }
-  static __device__ __forceinline__ void put_null(R* base, int q) { base[q] = R(0); }
-  static __device__ __forceinline__ Extra load_extra(const R* base, int s) { return Extra{base[s]}; }
+  // fp32 keeps the density twice, {f, f}: the packed accumulate then takes it as a register pair as it comes from LDS (the compiler
+  // copied the odd ones of four densities read together into fresh registers to broadcast them)
+  static constexpr bool DUP = std::is_same<R, float>::value;
+  static constexpr int XW = DUP ? 2 : 1;
+  struct Extra { R f, f2; };
+  static __device__ __forceinline__ void put_extra(R* base, int q, const R (&)[3], const R*, const R* f) {
+    if (DUP) { base[2 * q] = f[0]; base[2 * q + 1] = f[0]; }
+    else base[q] = f[0];
+  }
+  static __device__ __forceinline__ void put_null(R* base, int q) {
+    if (DUP) { base[2 * q] = R(0); base[2 * q + 1] = R(0); }
+    else base[q] = R(0);
+  }
+  static __device__ __forceinline__ Extra load_extra(const R* base, int s) { return DUP ? Extra{base[2 * s], base[2 * s + 1]} : Extra{base[s], R(0)}; }
   template <int MODE> static __device__ __forceinline__ void far_pair(R& acc, const R (&m2x)[3], R tt, const R (&b)[4], const Extra& e, const RsqConst<R>& K) {
     const R r2 = fma_(m2x[0], b[0], fma_(m2x[1], b[1], fma_(m2x[2], b[2], tt + b[3])));
     acc = fma_(e.f, (MODE == 1) ? rsqrt_newton2<false>(r2, K) : rsqrt_masked<MODE, false>(r2, K), acc);   // MODE 1: 2/r, as Ker::pair (acc_factor)
@@ -100,11 +123,11 @@ template <class R> struct CenteredFxU {      // u += f / r
   template <int MODE, int T> static __device__ __forceinline__ void far_pairs(R (&acc)[T], const R (&m2x)[T][3], const R (&tt)[T], const R (&b)[4], const Extra& e,
                                                                                 const RsqConst<R>& K) {
     if constexpr (std::is_same<R, float>::value && T == 2) {
-      f32x2 r2 = f32x2{tt[0], tt[1]} + f32x2{b[3], b[3]};
+      f32x2 r2 = pk_add_hi(f32x2{tt[0], tt[1]}, f32x2{b[2], b[3]});
       r2 = f32x2{m2x[0][2], m2x[1][2]} * f32x2{b[2], b[2]} + r2;
       r2 = f32x2{m2x[0][1], m2x[1][1]} * f32x2{b[1], b[1]} + r2;
       r2 = f32x2{m2x[0][0], m2x[1][0]} * f32x2{b[0], b[0]} + r2;
-      const f32x2 a = f32x2{acc[0], acc[1]} + f32x2{e.f, e.f} * rsqrt_pair<MODE>(r2);
+      const f32x2 a = f32x2{acc[0], acc[1]} + f32x2{e.f, e.f2} * rsqrt_pair<MODE>(r2);
       acc[0] = a[0]; acc[1] = a[1];
     } else {
 #pragma unroll
@@ -136,12 +159,12 @@ template <class R> struct CenteredDxU {      // u += ((x_t - x_s).n f) / r^3, wi
                                                                                 const RsqConst<R>& K) {
     if constexpr (std::is_same<R, float>::value && T == 2) {
       const f32x2 mx = {m2x[0][0], m2x[1][0]}, my = {m2x[0][1], m2x[1][1]}, mz = {m2x[0][2], m2x[1][2]};
-      f32x2 r2 = f32x2{tt[0], tt[1]} + f32x2{b[3], b[3]};
+      f32x2 r2 = pk_add_hi(f32x2{tt[0], tt[1]}, f32x2{b[2], b[3]});
       r2 = mz * f32x2{b[2], b[2]} + r2;
       r2 = my * f32x2{b[1], b[1]} + r2;
       r2 = mx * f32x2{b[0], b[0]} + r2;
       const f32x2 y = rsqrt_pair<MODE>(r2);
-      f32x2 dn = mz * f32x2{e.g[2], e.g[2]} + f32x2{e.g[3], e.g[3]};
+      f32x2 dn = pk_fma_lo_hi(mz, f32x2{e.g[2], e.g[3]});
       dn = my * f32x2{e.g[1], e.g[1]} + dn;
       dn = mx * f32x2{e.g[0], e.g[0]} + dn;
       const f32x2 a = f32x2{acc[0], acc[1]} + dn * (y * y * y);
