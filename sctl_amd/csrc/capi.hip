@@ -26,7 +26,7 @@ int comm_gather_to_device(sctl_amd_comm* c, const void* local, int64_t nbytes, v
 template <class R>
 hipError_t eval_centered(int kernel_id, int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* xn, const R* f, R* v_trg, double scale, int mode,
                          int cus, hipStream_t st, bool presorted);
-void centered_plan(int64_t Nt, int64_t Ns, int cus, int* T, int* splits, int64_t* chunk);
+void centered_plan(int64_t Nt, int64_t Ns, int cus, int src_bytes, int* T, int* splits, int64_t* chunk);
 namespace {
 
 thread_local std::string g_err;
@@ -1144,7 +1144,7 @@ int sctl_amd_eval_plan(int kernel, int real, int64_t Nt, int64_t Ns, int64_t Nt_
   if (use_centered(*k, real, Nt, Ns, Nt_whole)) {
     int T, splits;
     int64_t chunk;
-    centered_plan(Nt, Ns, cu_count(), &T, &splits, &chunk);
+    centered_plan(Nt, Ns, cu_count(), (real == SCTL_AMD_F64 ? 8 : 4) * (3 + k->nd + k->k0), &T, &splits, &chunk);
     if (trg_per_lane) *trg_per_lane = T;
     if (src_splits) *src_splits = splits;
     if (workgroups) *workgroups = ((Nt + 64 * T - 1) / (64 * T)) * splits;   // one wave64 per workgroup

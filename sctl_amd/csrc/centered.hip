@@ -28,16 +28,22 @@ template <class CP, class R, int MODE> void launch_centered(const EvalArgs<R>& a
 // waves are resident per CU; the work per wave varies with its share of near sources (0.5 % .. 34 % at 2^20 uniform
 // points), so the source range is split until there are >= 32 "rounds" of workgroups — measured on 2^20 x 2^20:
 // 1 split 517 ms, 4 splits 480 ms, 16 splits 469 ms (exact kernel on the same GPU: 520 ms).
-void centered_plan(int64_t Nt, int64_t Ns, int cus, int* T, int* splits, int64_t* chunk) {
+// Second rule (round 2): a split's source data (src_bytes per source: coordinates, density, normals as the kernel reads them) should fit the
+// 4 MB L2 of the XCD that owns the split (centered_kernel.hpp), i.e. <= 2 MB: at 2^23 fp32 sources in 2 splits every wave streamed 64 MB per
+// split through a 4 MB cache and the launch pulled 3.66 TB through the fabric (13 600 x the algorithmic bytes; PMC, profiles/r02_laplace_sl_f32_*).
+void centered_plan(int64_t Nt, int64_t Ns, int cus, int src_bytes, int* T, int* splits, int64_t* chunk) {
   *T = 2;   // one target per lane is LDS-bound (3 LDS reads per pair): 498 ms vs 465 ms at 2^20
   const int64_t wg_x = (Nt + kWaveBlock * 2 - 1) / (kWaveBlock * 2);
   const int64_t want = (int64_t)cus * 16 * 32;
   const int64_t ntile = (Ns + kWaveTile - 1) / kWaveTile;
   int64_t s = (want + wg_x - 1) / wg_x;
+  const int64_t s_l2 = (Ns * src_bytes + (2 << 20) - 1) / (2 << 20);
+  if (s < s_l2) s = s_l2;
 #ifdef SCTL_AMD_EXPERIMENTS   // timing experiments only (tools/): never defined for the shipped library
   if (const char* e = std::getenv("SCTL_AMD_EXPERIMENT_SPLITS")) s = std::atoi(e);
 #endif
   if (s > ntile / 64) s = ntile / 64;      // at least 64 tiles (4096 sources) per split
+  if (s > 8) s = (s + 7) & ~(int64_t)7;    // the XCD-aware mapping needs a multiple of 8
   if (s > 64) s = 64;
   if (s < 1) s = 1;
   const int64_t tiles_per = (ntile + s - 1) / s;
@@ -51,7 +57,7 @@ hipError_t eval_centered_t(int64_t Nt, int64_t Ns, const R* xt, const R* xs, con
   const R scale = (R)scale_d;
   int T, splits;
   int64_t chunk;
-  centered_plan(Nt, Ns, cus, &T, &splits, &chunk);
+  centered_plan(Nt, Ns, cus, (int)sizeof(R) * (3 + CP::Ker::ND + CP::Ker::K0), &T, &splits, &chunk);
   if (presorted) {   // the caller keeps the targets in Morton order (sctl_amd_op_*): no sort, no gather, results in place
     R* partial = nullptr;
     if (splits > 1) {
