@@ -89,6 +89,12 @@ def test_launch_planner():
         assert sctl_amd.plan("Laplace3D-FxU", 1, 1 << 20, 1 << 20)["path"] == "tile-centred"
         assert sctl_amd.plan("Laplace3D-DxU", 0, 1 << 20, 1 << 20)["path"] == "tile-centred"  # scalar Laplace kernels have a centred form
         assert sctl_amd.plan("Laplace3D-FxdU", 0, 1 << 20, 1 << 20)["path"] == "exact"        # the gradient needs x_t - x_s anyway
+        # a split's source data fits half an XCD's L2 (2 MB) and the splits come in eighths, one share per XCD (centered.hip)
+        for name, real, logn in (("Laplace3D-FxU", 1, 23), ("Laplace3D-FxU", 1, 21), ("Laplace3D-DxU", 0, 20), ("Laplace3D-FxU", 0, 21)):
+            p, i = sctl_amd.plan(name, real, 1 << logn, 1 << logn), sctl_amd.kernel_info(name)
+            per_source = (8 if real == 0 else 4) * (3 + i["nd"] + i["k0"])
+            assert p["src_splits"] % 8 == 0 and p["src_splits"] <= 64
+            assert (per_source << logn) / p["src_splits"] <= (2 << 20) or p["src_splits"] == 64
 
 
 def test_product_tree_never_touches_the_oracle():
