@@ -375,6 +375,8 @@ def main():
         torch.cuda.synchronize()
 
     op.set_targets(r_trg)            # the Morton order of the targets is set-up (cached per target set), like SetTrgCoord: never timed
+    if world > 1:                    # RCCL sets its channels up on a collective's first use: that is set-up too, whatever --warmup says
+        op.gather(r_trg, out_slab, out)
     for _ in range(args.warmup):
         step(False)
     fence()
