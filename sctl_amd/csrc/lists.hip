@@ -168,6 +168,8 @@ int sctl_amd_lists_eval_device(sctl_amd_lists* p, const void* r_trg, const void*
     return set_error(SCTL_AMD_ERR_BAD_CONTEXT, std::string(k.name) + " needs a context blob of " + std::to_string(k.ctx_bytes) + " bytes");
   if (p->nitems == 0) return SCTL_AMD_OK;
   if (!r_trg || !r_src || !v_src || !v_trg || (k.nd > 0 && !n_src)) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "null coordinate, normal, density or potential array");
+  DeviceScope scope(p->device);      // the work list lives on the plan's device: launch there whatever the caller's current device is
+  LISTS_TRY(scope.err);
   (void)hipGetLastError();
   const int mode = mode_for(p->real, digits);
   const double scale = k.scale / k.acc_factor[mode];
