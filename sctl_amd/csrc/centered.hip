@@ -19,7 +19,11 @@ namespace sctl_amd {
 
 namespace {
 template <class CP, class R, int MODE> void launch_centered(const EvalArgs<R>& a, dim3 grid, hipStream_t st) {
+#if defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_FAR_UNR)   // A/B builds: far records per unrolled group
+  hipLaunchKernelGGL((centered_kernel<CP, R, MODE, 2, SCTL_AMD_EXP_FAR_UNR>), grid, dim3(kWaveBlock), 0, st, a);
+#else
   hipLaunchKernelGGL((centered_kernel<CP, R, MODE, 2>), grid, dim3(kWaveBlock), 0, st, a);
+#endif
 }
 }  // namespace
 

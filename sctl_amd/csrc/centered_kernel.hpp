@@ -115,6 +115,10 @@ template <class R> struct CenteredFxU {      // u += f / r
     else base[q] = R(0);
   }
   static __device__ __forceinline__ Extra load_extra(const R* base, int s) { return DUP ? Extra{base[2 * s], base[2 * s + 1]} : Extra{base[s], R(0)}; }
+  static __device__ __forceinline__ void store_extra(R* base, int q, const Extra& e) {
+    if (DUP) { base[2 * q] = e.f; base[2 * q + 1] = e.f2; }
+    else base[q] = e.f;
+  }
   template <int MODE> static __device__ __forceinline__ void far_pair(R& acc, const R (&m2x)[3], R tt, const R (&b)[4], const Extra& e, const RsqConst<R>& K) {
     const R r2 = fma_(m2x[0], b[0], fma_(m2x[1], b[1], fma_(m2x[2], b[2], tt + b[3])));
     acc = fma_(e.f, (MODE == 1) ? rsqrt_newton2<false>(r2, K) : rsqrt_masked<MODE, false>(r2, K), acc);   // MODE 1: 2/r, as Ker::pair (acc_factor)
@@ -148,6 +152,9 @@ template <class R> struct CenteredDxU {      // u += ((x_t - x_s).n f) / r^3, wi
     Extra e;
     Rec4<R>::get((const typename Rec4<R>::V*)base + s * Rec4<R>::NW, e.g);
     return e;
+  }
+  static __device__ __forceinline__ void store_extra(R* base, int q, const Extra& e) {
+    Rec4<R>::put((typename Rec4<R>::V*)base + q * Rec4<R>::NW, e.g[0], e.g[1], e.g[2], e.g[3]);
   }
   template <int MODE> static __device__ __forceinline__ void far_pair(R& acc, const R (&m2x)[3], R tt, const R (&b)[4], const Extra& e, const RsqConst<R>& K) {
     const R r2 = fma_(m2x[0], b[0], fma_(m2x[1], b[1], fma_(m2x[2], b[2], tt + b[3])));
@@ -187,8 +194,8 @@ __global__ void __launch_bounds__(kWaveBlock) centered_kernel(const EvalArgs<R> 
   constexpr int ND = Ker::ND;
   constexpr int NEARW = (Ker::NREC + 3) / 4;                  // Rec4 groups of a near record (the kernel's packed exact record)
   constexpr int XV = (CP::XW * (int)sizeof(R) + 15) / 16;     // 16-byte words of the extra far record
-  __shared__ V farB[(kWaveTile + 4) * NW];                    // {x', y', z', |x_s'|^2}   (+ padding records)
-  __shared__ V farXv[(kWaveTile + 4) * (XV > 0 ? XV : 1)];    // the policy's extra far reals (density, or the normal terms)
+  __shared__ V farB[(kWaveTile + UNR) * NW];                  // {x', y', z', |x_s'|^2}   (+ the leftovers of earlier tiles)
+  __shared__ V farXv[(kWaveTile + UNR) * (XV > 0 ? XV : 1)];    // the policy's extra far reals (density, or the normal terms)
   __shared__ V nearA[(kNearCap + 2) * NW * NEARW];            // packed exact records; near sources are collected over
                                                               // several tiles and evaluated in batches, so the exact loop runs
                                                               // rarely and with a long trip count
@@ -310,9 +317,10 @@ __global__ void __launch_bounds__(kWaveBlock) centered_kernel(const EvalArgs<R> 
     nn = 0;
   };
 
-  for (int it = 0; it < ntile; it++) {
+  // One tile: classify each source as far / near, compact the two lists (far records behind the `carry` left over from earlier tiles), start
+  // the loads of the next tile.  Returns the number of far sources of this tile.
+  auto stage_tile = [&](int it, int carry) -> int {
     const int ns = (it == ntile - 1) ? (int)(len - (int64_t)it * kWaveTile) : kWaveTile;
-    // ---- stage one tile: classify each source as far / near and compact the two lists --------------------
     const bool valid = lane < ns;
     const R p[3] = {x[0] - c[0], x[1] - c[1], x[2] - c[2]};
     const R ss = len2(p);
@@ -327,27 +335,22 @@ __global__ void __launch_bounds__(kWaveBlock) centered_kernel(const EvalArgs<R> 
       __syncthreads();
     }
     if (is_far) {
-      const int q = __popcll(bf & below);
+      const int q = carry + __popcll(bf & below);
       Rec4<R>::put(farB + q * NW, p[0], p[1], p[2], ss);
       CP::put_extra(farX, q, p, nrm, f);
     } else if (is_near) {
       put_near(nn + __popcll(bn & below), x, nrm, f);
     }
     nn += nnear;
-    // pad the far list to a multiple of UNR with null sources (zero density at ~1e3 cluster radii): they contribute
-    // exactly 0 and remove the low-ILP remainder loop
-    if (lane < UNR - 1) {
-      const int q = nfar + lane;
-      if (q < ((nfar + UNR - 1) & ~(UNR - 1))) { Rec4<R>::put(farB + q * NW, far_off, R(0), R(0), far_off * far_off); CP::put_null(farX, q); }
-    }
-    if (it + 1 < ntile) load_source(it + 1);
-    __syncthreads();
-
-    // ---- far sources: 4-instruction distance, no mask -------------------------------------------------------
-    R tacc[T];   // per-tile partial sums, folded into acc once per tile (two-level summation: matters for fp32 at Ns = 2^23)
+    return nfar;
+  };
+  // records [0, m) of the far list, m a multiple of UNR: the 4-instruction distance, no mask.  Per-call partial sums, folded into acc at the
+  // end (two-level summation: matters for fp32 at Ns = 2^23)
+  auto run_far = [&](int m) {
+    R tacc[T];
 #pragma unroll
     for (int j = 0; j < T; j++) tacc[j] = 0;
-    for (int s = 0; s < nfar; s += UNR) {
+    for (int s = 0; s < m; s += UNR) {
 #pragma unroll
       for (int u = 0; u < UNR; u++) {
         R b[4];
@@ -358,6 +361,42 @@ __global__ void __launch_bounds__(kWaveBlock) centered_kernel(const EvalArgs<R> 
     }
 #pragma unroll
     for (int j = 0; j < T; j++) acc[j][0] += tacc[j];
+  };
+  auto put_null_far = [&](int q) { Rec4<R>::put(farB + q * NW, far_off, R(0), R(0), far_off * far_off); CP::put_null(farX, q); };   // zero density at ~1e3 cluster radii: contributes exactly 0
+
+  // The far list is consumed UNR records at a time.  fp64: what is left over (< UNR) moves to the front of the list for the next tile instead
+  // of being padded with null sources (1.5 evaluations in ~62 per tile): +0.9 % (A/B, profiles/r02_ab_far_carry.txt).  fp32, whose tile
+  // costs a third of the cycles, gains nothing from it and pads every tile.
+  if constexpr (sizeof(R) == 8) {
+    int carry = 0;   // far records left over from the previous tiles (wave-uniform, < UNR)
+    for (int it = 0; it < ntile; it++) {
+      const int n = carry + stage_tile(it, carry), m = n & ~(UNR - 1);
+      if (it + 1 < ntile) load_source(it + 1);
+      __syncthreads();
+      run_far(m);
+      carry = n - m;
+      if (m > 0 && lane < carry) {   // the leftovers to the front (one wave: its LDS operations complete in program order)
+        R b[4];
+        Rec4<R>::get(farB + (m + lane) * NW, b);
+        const typename CP::Extra e = CP::load_extra(farX, m + lane);
+        Rec4<R>::put(farB + lane * NW, b[0], b[1], b[2], b[3]);
+        CP::store_extra(farX, lane, e);
+      }
+    }
+    __syncthreads();
+    if (carry > 0) {   // the last leftovers, padded once
+      if (lane < UNR - carry) put_null_far(carry + lane);
+      __syncthreads();
+      run_far(UNR);
+    }
+  } else {
+    for (int it = 0; it < ntile; it++) {
+      const int nfar = stage_tile(it, 0), padded = (nfar + UNR - 1) & ~(UNR - 1);
+      if (lane < UNR - 1 && nfar + lane < padded) put_null_far(nfar + lane);
+      if (it + 1 < ntile) load_source(it + 1);
+      __syncthreads();
+      run_far(padded);
+    }
   }
   __syncthreads();
   flush_near();
