@@ -25,7 +25,13 @@ def short(name):
     return name[:90]
 
 
-rows = list(csv.DictReader(open(glob.glob(P + "/trace/runc/*_kernel_stats.csv")[0])))
+def newest(pattern):
+    """gpurun merges every call's files into the same directory: take the latest run's."""
+    found = glob.glob(pattern)
+    return max(found, key=os.path.getmtime) if found else None
+
+
+rows = list(csv.DictReader(open(newest(P + "/trace/runc/*_kernel_stats.csv"))))
 with open("profiles/%s_kernel_stats.csv" % tag, "w") as fh:
     fh.write("# rocprofv3 --kernel-trace --stats of: python bench.py --steps 3 --warmup 1 --no-cpu-baseline (workload %s)\n" % workload)
     fh.write("kernel,calls,total_ns,average_ns,percentage\n")
@@ -37,10 +43,10 @@ summ = collections.defaultdict(dict)
 meta = {}
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_clk"):
     agg = collections.defaultdict(list)
-    found = glob.glob("%s/%s/runc/*_counter_collection.csv" % (P, sub))
+    found = newest("%s/%s/runc/*_counter_collection.csv" % (P, sub))
     if not found:
         continue
-    for r in csv.DictReader(open(found[0])):
+    for r in csv.DictReader(open(found)):
         if "at::native" in r["Kernel_Name"]:
             continue
         k = short(r["Kernel_Name"])
