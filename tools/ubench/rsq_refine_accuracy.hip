@@ -30,7 +30,8 @@ int main() {
   CHECK(hipMalloc(&dx, n * 8)); CHECK(hipMalloc(&d0, n * 8)); CHECK(hipMalloc(&d1, n * 8)); CHECK(hipMalloc(&d2, n * 8));
   std::mt19937_64 g(7);
   std::uniform_real_distribution<double> U(0.0, 1.0), E(-600, 600);
-  double m0 = 0, m1 = 0, m2 = 0, s0 = 0, s1 = 0, s2 = 0, lo1 = 0, hi1 = 0, bias1 = 0;
+  double m0 = 0, m1 = 0, m2 = 0, s0 = 0, s1 = 0, s2 = 0, lo1 = 0, hi1 = 0, bias1 = 0, lo0 = 0, hi0 = 0, bias0 = 0;
+  double lo0p[2] = {0, 0}, hi0p[2] = {0, 0};   // seed error by exponent parity of the argument
   long long cnt = 0;
   for (int r = 0; r < rounds; r++) {
     for (int i = 0; i < n; i++) {
@@ -47,13 +48,16 @@ int main() {
       const long double ex = 1.0L / sqrtl((long double)x[i]);
       const double e0 = (double)((h0[i] - ex) / ex), e1 = (double)((h1[i] - ex) / ex), e2 = (double)((h2[i] - ex) / ex);
       m0 = fmax(m0, fabs(e0)); m1 = fmax(m1, fabs(e1)); m2 = fmax(m2, fabs(e2));
-      s0 += e0 * e0; s1 += e1 * e1; s2 += e2 * e2; bias1 += e1;
+      s0 += e0 * e0; s1 += e1 * e1; s2 += e2 * e2; bias1 += e1; bias0 += e0;
+      lo0 = fmin(lo0, e0); hi0 = fmax(hi0, e0);
+      { int ex; (void)frexp(x[i], &ex); const int par = ex & 1; lo0p[par] = fmin(lo0p[par], e0); hi0p[par] = fmax(hi0p[par], e0); }
       lo1 = fmin(lo1, e1); hi1 = fmax(hi1, e1);
       cnt++;
     }
   }
   printf("%lld arguments\n", cnt);
-  printf("MODE 0 seed  (v_rsq_f64):        max rel err %.3e (2^%.2f), rms %.3e\n", m0, log2(m0), sqrt(s0 / cnt));
+  printf("MODE 0 seed  (v_rsq_f64):        max rel err %.3e (2^%.2f), rms %.3e, mean %.3e, range [%.3e, %.3e]; by exponent parity [%.3e, %.3e] / [%.3e, %.3e]\n", m0, log2(m0),
+         sqrt(s0 / cnt), bias0 / cnt, lo0, hi0, lo0p[0], hi0p[0], lo0p[1], hi0p[1]);
   printf("MODE 1 Newton (unnormalised):    max rel err %.3e (2^%.2f), rms %.3e, mean %.3e, range [%.3e, %.3e]; 3/2 d_max^2 = %.3e\n", m1, log2(m1), sqrt(s1 / cnt),
          bias1 / cnt, lo1, hi1, 1.5 * m0 * m0);
   printf("MODE 2 Halley:                   max rel err %.3e (2^%.2f = %.2f ulp), rms %.3e\n", m2, log2(m2), m2 / 1.1102230246251565e-16, sqrt(s2 / cnt));
