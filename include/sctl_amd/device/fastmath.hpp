@@ -116,10 +116,11 @@ SCTL_AMD_HD double exp_fast(double x, const Coeffs& K) {
 //           (33-bit head, exact product for |n| < 2^20, i.e. |x| < 1.2e4): the ABSOLUTE error stays ~1e-16, which is what a
 //           kernel value cos + i sin of unit modulus needs; larger arguments take the libm path in the caller.
 //   exp:    nodes 2^(j/64), x = n ln2/64 + r, |r| <= ln2/128, e^r - 1 by a degree-5 polynomial (truncation 3.5e-17 rel).
-// 16 + 15 fp64 issue slots against 28 + 24 for the table-free code.
+// 16 + 15 fp64 issue slots against 28 + 24 for the table-free code; 14 + 11 for the forms with the wavenumber folded in (below).
 constexpr int kTrigNodes = 512, kExpNodes = 64;
 constexpr int kTableDoubles = 2 * kTrigNodes + kExpNodes;   // [sin_j, cos_j] pairs, then 2^(j/64)
 constexpr double kSincosTabMaxArg = 1.2e4;
+constexpr double kExpTabMaxArg = 1.0e6;   // exp_tab_k: the integer part 64 x / ln2 must stay within 31 bits; from |x| = 746 on the result is 0 or inf
 
 struct TabCoeffs {
   double inv_h, h1, h2, s1, s2, c1, c2, inv_e, e1, e2, p2, p3, p4;
@@ -199,6 +200,74 @@ SCTL_AMD_HD double exp_tab_clamped(double xc, const TabCoeffs& K, const double* 
   p = fma_(p, r, 0.5);
   const double em1 = fma_(r * r, p, r);
   return __builtin_ldexp(fma_(t, em1, t), ni >> 6);
+}
+
+// ---- the same two functions of x = k r, with the constant k folded into the reduction and the polynomial --------------------------
+// The Helmholtz kernel needs sincos(kr r) and exp(kappa r) for ONE wavenumber per launch and a distance r per pair.  Forming
+// x = k r first costs a multiplication per pair and function; instead the period is divided by k once per launch:
+//   r = n (pi/256)/kr + y,  sin(kr y) = y (kr + z (S1 + S2 z)),  cos(kr y) - 1 = z (C1 + C2 z),  z = y^2,  S1 = -kr^3/6, ...
+//   r = n (ln2/64)/kappa + q,  e^(kappa q) - 1 = q (P1 + q (P2 + q (P3 + q (P4 + q P5)))),  P_m = kappa^m / m!
+// (the quotients as two-piece values, so that the reduced argument is as exact as before).  The rounding of x = k r itself
+// disappears; everything else is operation for operation the code above.  k = 0 gives n = 0 and the value at 0.
+struct TabCoeffsK {
+  double ih, h1, h2, s0, s1, s2, c1, c2;    // sincos(kr r)
+  double ie, e1, e2, p1, p2, p3, p4, p5;    // exp(kappa r)
+  // (hi + lo) / d as a two-piece quotient
+  static SCTL_AMD_HD void div2(double hi, double lo, double d, double& q1, double& q2) {
+    q1 = hi / d;
+    q2 = (fma_(-q1, d, hi) + lo) / d;
+  }
+  SCTL_AMD_HD void set(double kr, double kappa, const TabCoeffs& B) {
+    ih = B.inv_h * kr;
+    if (kr != 0) div2(B.h1, B.h2, kr, h1, h2); else h1 = h2 = 0;
+    const double k2 = kr * kr;
+    s0 = kr; s1 = B.s1 * k2 * kr; s2 = B.s2 * k2 * k2 * kr;
+    c1 = B.c1 * k2; c2 = B.c2 * k2 * k2;
+    ie = B.inv_e * kappa;
+    if (kappa != 0) div2(B.e1, B.e2, kappa, e1, e2); else e1 = e2 = 0;
+    const double a2 = kappa * kappa;
+    p1 = kappa; p2 = 0.5 * a2; p3 = B.p2 * a2 * kappa; p4 = B.p3 * a2 * a2; p5 = B.p4 * a2 * a2 * kappa;
+  }
+#ifdef __HIPCC__
+  // the values were computed by vector instructions (the same in every lane): move them to scalar registers first
+  static __device__ __forceinline__ void to_sgpr(double& v) {
+    v = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+  }
+  __device__ __forceinline__ void pin() {
+    to_sgpr(ih); to_sgpr(h1); to_sgpr(h2); to_sgpr(s0); to_sgpr(s1); to_sgpr(s2); to_sgpr(c1); to_sgpr(c2);
+    to_sgpr(ie); to_sgpr(e1); to_sgpr(e2); to_sgpr(p1); to_sgpr(p2); to_sgpr(p3); to_sgpr(p4); to_sgpr(p5);
+  }
+#endif
+};
+
+// sincos(kr r); precondition |kr| r <= kSincosTabMaxArg
+SCTL_AMD_HD void sincos_tab_k(double r, double& s, double& c, const TabCoeffsK& K, const double* table) {
+  const double t = fma_(r, K.ih, kRoundMagic);
+  const double n = t - kRoundMagic;
+  double y = fma_(n, K.h1, r);
+  y = fma_(n, K.h2, y);
+  const int j = low_dword(t) & (kTrigNodes - 1);
+  const double sj = table[2 * j], cj = table[2 * j + 1];
+  const double z = y * y;
+  const double sy = y * fma_(z, fma_(z, K.s2, K.s1), K.s0);
+  const double cm1 = z * fma_(z, K.c2, K.c1);
+  s = fma_(sj, cm1, fma_(cj, sy, sj));
+  c = fma_(cj, cm1, fma_(-sj, sy, cj));
+}
+
+// exp(kappa r); precondition |kappa| r <= kExpTabMaxArg (the caller's end-of-tile check); 0 / inf beyond the double range, NaN in -> NaN out
+SCTL_AMD_HD double exp_tab_k(double r, const TabCoeffsK& K, const double* table) {
+  const double tm = fma_(r, K.ie, kRoundMagic);
+  const double n = tm - kRoundMagic;
+  double q = fma_(n, K.e1, r);
+  q = fma_(n, K.e2, q);
+  const int ni = low_dword(tm);
+  const double t = table[2 * kTrigNodes + (ni & (kExpNodes - 1))];
+  double p = fma_(K.p5, q, K.p4);
+  p = fma_(p, q, K.p3);
+  p = fma_(p, q, K.p2);
+  p = fma_(p, q, K.p1);
+  return __builtin_ldexp(fma_(t, p * q, t), ni >> 6);
 }
 
 SCTL_AMD_HD double exp_tab(double x, const TabCoeffs& K, const double* table) {

@@ -16,6 +16,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "fastmath.hpp"
 
@@ -106,21 +107,32 @@ template <> struct HelmholtzConsts<double> {         // fp64: table-driven sinco
   static constexpr bool HAS_VARIANT = true;            // VARIANT = real wavenumber: no exponential
   __device__ __forceinline__ bool variant(const KerCtx& ctx) const { return ctx.v[1] == 0; }
   RsqConst<double> rsq;
-  fastmath::TabCoeffs tc;
+  fastmath::TabCoeffsK tk;     // reduction and polynomial constants with the launch's wavenumber folded in: functions of the distance
   const double* table;
-  __device__ __forceinline__ explicit HelmholtzConsts(double* lds) : table(lds) {
+  // (a Consts type constructible from (double*, const KerCtx&) is handed the launch's context: make_consts below)
+  __device__ __forceinline__ HelmholtzConsts(double* lds, const KerCtx& ctx) : table(lds) {
     {
       const fastmath::Coeffs full;                   // the table-free polynomials, used here only
       fastmath::fill_tables(lds, (int)threadIdx.x, (int)blockDim.x, full);
     }
     __syncthreads();
-    tc.pin();
+    tk.set(ctx.v[0], -ctx.v[1], fastmath::TabCoeffs());
+    tk.pin();
   }
-  // the table-driven sincos needs |Re k| r <= kSincosTabMaxArg: the speculative pass only tracks the largest distance
+  // the table-driven forms need |Re k| r <= kSincosTabMaxArg and |Im k| r <= kExpTabMaxArg: the speculative pass only tracks the largest
+  // distance
   mutable double rmax = 0;
   __device__ __forceinline__ void begin_tile() const { rmax = 0; }
-  __device__ __forceinline__ bool tile_bad(const KerCtx& ctx) const { return !(__builtin_fabs(ctx.v[0]) * rmax <= fastmath::kSincosTabMaxArg); }
+  __device__ __forceinline__ bool tile_bad(const KerCtx& ctx) const {
+    return !(__builtin_fabs(ctx.v[0]) * rmax <= fastmath::kSincosTabMaxArg && __builtin_fabs(ctx.v[1]) * rmax <= fastmath::kExpTabMaxArg);
+  }
 };
+
+// Per-kernel constants of a launch: Consts(lds, ctx) when the type takes the context, Consts(lds) otherwise.
+template <class KC> __device__ __forceinline__ KC make_consts(double* lds, const KerCtx& ctx) {
+  if constexpr (std::is_constructible<KC, double*, const KerCtx&>::value) return KC(lds, ctx);
+  else return KC(lds);
+}
 
 template <class R> __device__ __forceinline__ R fma_(R a, R b, R c);
 template <> __device__ __forceinline__ double fma_<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
@@ -321,31 +333,32 @@ struct Helmholtz3D_FxU {
     const R rinv = rsqrt_masked<MODE, MASKED>(r2, K.rsq);
     const R r = r2 * rinv;
     R sn, cs;
-    sincos_<MASKED>(R(ctx.v[0]) * r, r, sn, cs, K);
+    sincos_<MASKED>(r, ctx, sn, cs, K);
     R amp = rinv;
-    if (!REAL_K) amp *= exp_(r, ctx, K);
+    if (!REAL_K) amp *= exp_<MASKED>(r, ctx, K);
     const R gr = amp * cs, gi = amp * sn;
     acc[0] = fma_(gr, rec[3], fma_(-gi, rec[4], acc[0]));
     acc[1] = fma_(gi, rec[3], fma_(gr, rec[4], acc[1]));
   }
-  // fp64: Cody-Waite reduction to the nearest node of an LDS table + a short polynomial (fastmath.hpp).  Arguments beyond
-  // 1.2e4 (two thousand wavelengths) need libm: the speculative pass (MASKED = false) runs the table path unconditionally,
-  // as straight-line code, and only records the largest distance (one v_max_f64) for the end-of-tile check; the careful pass
-  // branches per pair.
-  template <bool MASKED> static __device__ __forceinline__ void sincos_(double x, double r, double& s, double& c, const HelmholtzConsts<double>& K) {
+  // fp64: Cody-Waite reduction to the nearest node of an LDS table + a short polynomial (fastmath.hpp).  The speculative pass
+  // (MASKED = false) runs the forms with the wavenumber folded in, unconditionally, as straight-line code, and only records the
+  // largest distance (one v_max_f64) for the end-of-tile check; a tile with |Re k| r > 1.2e4 (two thousand wavelengths) or
+  // |Im k| r > 700 is re-run by the careful pass, which branches per pair (libm beyond the table's range).
+  template <bool MASKED> static __device__ __forceinline__ void sincos_(double r, const KerCtx& ctx, double& s, double& c, const HelmholtzConsts<double>& K) {
     if (!MASKED) {
       K.rmax = __builtin_fmax(K.rmax, r);
-      fastmath::sincos_tab(x, s, c, K.tc, K.table);
-    } else if (__builtin_expect(__builtin_fabs(x) > fastmath::kSincosTabMaxArg, 0)) {
-      ::sincos(x, &s, &c);
-    } else {
-      fastmath::sincos_tab(x, s, c, K.tc, K.table);
+      fastmath::sincos_tab_k(r, s, c, K.tk, K.table);
+      return;
     }
+    const double x = ctx.v[0] * r;
+    if (__builtin_expect(__builtin_fabs(x) > fastmath::kSincosTabMaxArg, 0)) ::sincos(x, &s, &c);
+    else fastmath::sincos_tab_k(r, s, c, K.tk, K.table);
   }
   // fp32: the hardware's sine / cosine / exp2 (v_sin_f32, v_cos_f32, v_exp_f32: ~1e-6 absolute, inputs in revolutions / powers of
   // two) behind a two-piece reduction, so that the reduced argument keeps 24 bits however many periods x spans.  The phase
   // error that remains is the rounding of x itself (|x| 6e-8), which libm's exact reduction cannot remove either.
-  template <bool MASKED> static __device__ __forceinline__ void sincos_(float x, float, float& s, float& c, const HelmholtzConsts<float>&) {
+  template <bool MASKED> static __device__ __forceinline__ void sincos_(float r, const KerCtx& ctx, float& s, float& c, const HelmholtzConsts<float>&) {
+    const float x = float(ctx.v[0]) * r;
     const float c_hi = 0.15915494f, c_lo = 6.4206383e-9f;       // 1/(2 pi) = c_hi + c_lo
     const float n = __builtin_rintf(x * c_hi);
     float fr = __builtin_fmaf(x, c_hi, -n);
@@ -355,11 +368,13 @@ struct Helmholtz3D_FxU {
   }
   // exp(-Im k r): r >= 0 is clamped to 800/|Im k| (one v_min_f64; a NaN distance turns into the cap, but then rinv is NaN
   // too and the product stays NaN), so the argument handed to the table code is within its +-800 range
-  static __device__ __forceinline__ double exp_(double r, const KerCtx& ctx, const HelmholtzConsts<double>& K) {
-    const double rc = __builtin_fmin(r, 800.0 / __builtin_fabs(ctx.v[1]));
-    return fastmath::exp_tab_clamped(-ctx.v[1] * rc, K.tc, K.table);
+  template <bool MASKED> static __device__ __forceinline__ double exp_(double r, const KerCtx& ctx, const HelmholtzConsts<double>& K) {
+    if (!MASKED) return fastmath::exp_tab_k(r, K.tk, K.table);   // range checked at the end of the tile (tile_bad)
+    // careful pass: r >= 0 clamped to kExpTabMaxArg / |Im k| — the value there is 0 or inf already (a NaN distance turns into the cap, but
+    // then rinv is NaN too and the product stays NaN)
+    return fastmath::exp_tab_k(__builtin_fmin(r, fastmath::kExpTabMaxArg / __builtin_fabs(ctx.v[1])), K.tk, K.table);
   }
-  static __device__ __forceinline__ float exp_(float r, const KerCtx& ctx, const HelmholtzConsts<float>&) {
+  template <bool MASKED> static __device__ __forceinline__ float exp_(float r, const KerCtx& ctx, const HelmholtzConsts<float>&) {
     const float x = -float(ctx.v[1]) * r;
     const float l_hi = 1.4426950f, l_lo = 1.9259630e-8f;        // log2(e) = l_hi + l_lo
     const float n = __builtin_fminf(__builtin_fmaxf(__builtin_rintf(x * l_hi), -300.0f), 300.0f);

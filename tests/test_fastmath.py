@@ -8,7 +8,7 @@ from conftest import ROOT
 
 def test_fastmath_against_libm(tmp_path):
     exe = str(tmp_path / "fastmath_check")
-    subprocess.run(["g++", "-O2", "-std=c++14", "-ffp-contract=off", os.path.join(ROOT, "tests", "cpp", "fastmath_check.cpp"), "-o", exe], check=True)
+    subprocess.run(["g++", "-O2", "-std=c++14", "-ffp-contract=off", os.path.join(ROOT, "tests", "cpp", "fastmath_check.cpp"), "-o", exe, "-lquadmath"], check=True)
     out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout
     v = {k: float(x) for k, x in re.findall(r"(\w+) ([0-9.e+-]+)", out)}
     assert v["max_abs_err_sin"] < 4e-16 and v["max_abs_err_cos"] < 4e-16      # |x| up to 1.5e6
@@ -17,3 +17,5 @@ def test_fastmath_against_libm(tmp_path):
     # the table-driven forms the device loop runs (tables filled by the polynomial code, as a workgroup does)
     assert v["tab_abs_err_sin"] < 4e-16 and v["tab_abs_err_cos"] < 4e-16      # |x| up to 1.2e4
     assert v["tab_rel_err_exp"] < 4e-16 and v["tab_specials"] == 1
+    # the same with the launch's wavenumber folded into the reduction (what the speculative pass runs): six (Re k, -Im k) pairs incl. 0
+    assert v["k_abs_err_sin"] < 4e-16 and v["k_abs_err_cos"] < 4e-16 and v["k_rel_err_exp"] < 4e-16 and v["k_specials"] == 1
