@@ -25,6 +25,9 @@
 // and may produce inf/NaN for d = 0 when !MASKED (the evaluator detects that per tile and re-runs the tile masked).  MODE is the
 // accuracy request: 0 >= 7 digits, 1 >= 14 digits, 2 full precision of R.  The context (ctx.v, up to 4 doubles) is the
 // functor's ctx_ptr payload, copied at launch.
+// A kernel with per-launch constants of its own supplies a Consts type instead of DefaultConsts: it is built once per workgroup from
+// (double* lds) or, when it has such a constructor, from (double* lds, const KerCtx& ctx) — e.g. to derive scalar-register constants
+// from a wavenumber (ukernels.hpp: HelmholtzConsts) — and handed to every pair() call.
 //
 // Build:  hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -I<repo>/include my_kernel.hip -o libmy_kernel.so -L<repo>/sctl_amd -lsctl_amd
 // Use:    sctl_amd_load_plugin("libmy_kernel.so")  (or link the object into the program), then sctl_amd_kernel_id("Yukawa3D-FxU");
