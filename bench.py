@@ -405,7 +405,7 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "pair-interactions/s, Laplace-SL N x N direct sum" if args.workload.startswith("laplace_sl") else "pair-interactions/s",
+            "metric": "pair-interactions/s, Laplace-SL N x N direct sum" if kernel == "Laplace3D-FxU" else "pair-interactions/s",
             "value": value, "unit": "pair-interactions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": dtype, "data": "synthetic",

@@ -213,8 +213,8 @@ struct Stokes3D_FxU {
   }
   template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const Consts<R>& K) {
     const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K.rsq);
-    const R t = dot3(d, rec + 3) * (rinv * rinv * rinv);
-    for (int j = 0; j < 3; j++) acc[j] = fma_(t, d[j], fma_(rinv, rec[3 + j], acc[j]));
+    const R t = dot3(d, rec + 3) * (rinv * rinv);                                              // (r.f) / r^2
+    for (int j = 0; j < 3; j++) acc[j] = fma_(rinv, fma_(t, d[j], rec[3 + j]), acc[j]);       // (f_j + r_j (r.f) / r^2) / r: 1/r^3 is never formed
   }
 };
 
@@ -270,8 +270,8 @@ struct Stokes3D_FSxU {
   }
   template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const Consts<R>& K) {
     const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K.rsq);
-    const R t = (dot3(d, rec + 3) + rec[6]) * (rinv * rinv * rinv);
-    for (int j = 0; j < 3; j++) acc[j] = fma_(t, d[j], fma_(rinv, rec[3 + j], acc[j]));
+    const R t = (dot3(d, rec + 3) + rec[6]) * (rinv * rinv);
+    for (int j = 0; j < 3; j++) acc[j] = fma_(rinv, fma_(t, d[j], rec[3 + j]), acc[j]);
   }
 };
 
@@ -287,19 +287,23 @@ struct Stokes3D_FxUP {
   }
   template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const Consts<R>& K) {
     const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K.rsq);
-    const R t = dot3(d, rec + 3) * (rinv * rinv * rinv);
-    for (int j = 0; j < 3; j++) acc[j] = fma_(t, d[j], fma_(rinv, rec[3 + j], acc[j]));
-    acc[3] += t;
+    const R t = dot3(d, rec + 3) * (rinv * rinv);
+    for (int j = 0; j < 3; j++) acc[j] = fma_(rinv, fma_(t, d[j], rec[3 + j]), acc[j]);
+    acc[3] = fma_(t, rinv, acc[3]);
   }
 };
 
 // ---- NEW: Laplace single + double layer -> potential and gradient (BASELINE config 2) -----
 //   u      = q / r + mu (r.n) / r^3
 //   grad u = -q r / r^3 + mu ( n / r^3 - 3 (r.n) r / r^5 ),    scale 1/(4 pi);  record holds m = mu * n and q.
+template <class R> struct FDxUdUConsts : DefaultConsts<R> {   // + the constant 3 in a register for the whole kernel (no inline constant; re-made per source otherwise)
+  R c3;
+  __device__ __forceinline__ explicit FDxUdUConsts(double* lds) : DefaultConsts<R>(lds), c3(R(3)) { asm volatile("" : "+v"(c3)); }
+};
 struct Laplace3D_FDxUdU {
   static constexpr int ID = 8, K0 = 2, K1 = 4, ND = 3, NREC = 8, FLOPS = 28;
   static constexpr const char* NAME = "Laplace3D-FDxUdU";
-  template <class R> using Consts = DefaultConsts<R>;
+  template <class R> using Consts = FDxUdUConsts<R>;
   static constexpr double scale() { return 1 / (4 * kPi); }
   static constexpr double acc_factor(int /*mode*/) { return 1; }   // what pair() accumulates, relative to the kernel value
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R* n, const R* f) {
@@ -310,10 +314,10 @@ struct Laplace3D_FDxUdU {
     const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K.rsq);
     const R rinv2 = rinv * rinv;
     const R rinv3 = rinv2 * rinv;
-    const R a = dot3(d, rec + 3) * rinv3;               // mu (r.n) / r^3
-    acc[0] = fma_(rec[6], rinv, acc[0]) + a;
-    const R b = fma_(R(-3) * a, rinv2, -(rec[6] * rinv3));   // -(q / r^3 + 3 mu (r.n) / r^5)
-    for (int j = 0; j < 3; j++) acc[1 + j] = fma_(d[j], b, fma_(rec[3 + j], rinv3, acc[1 + j]));
+    const R w = dot3(d, rec + 3) * rinv2;               // mu (r.n) / r^2
+    acc[0] = fma_(w, rinv, fma_(rec[6], rinv, acc[0]));   // q / r + mu (r.n) / r^3
+    const R c = fma_(w, K.c3, rec[6]);                  // q + 3 mu (r.n) / r^2
+    for (int j = 0; j < 3; j++) acc[1 + j] = fma_(rinv3, fma_(-d[j], c, rec[3 + j]), acc[1 + j]);   // (m_j - r_j c) / r^3
   }
 };
 
