@@ -196,6 +196,7 @@ __global__ void __launch_bounds__(kBlock) SCTL_AMD_EVAL_ATTR eval_kernel(const E
 #pragma unroll
   for (int j = 0; j < T; j++) {
     const int64_t t = tbase + j * kBlock + tid;
+    finish_acc<Ker, R>(acc[j]);
     if (t < a.Nt) {
       if (gridDim.y == 1) {
 #pragma unroll
@@ -246,6 +247,7 @@ __global__ void __launch_bounds__(kBlock) matrix_kernel(int64_t Nt, int64_t Ns, 
     for (int k = 0; k < K1; k++) acc[k] = 0;
     Ker::template pack<R>(rec, x, n, f);
     Ker::template pair<R, MODE, true>(acc, d, rec, ctx, K);
+    finish_acc<Ker, R>(acc);
     R* row = M + ((s * K0 + k0) * Nt + t) * K1;
 #pragma unroll
     for (int k = 0; k < K1; k++) row[k] = acc[k] * scale;
@@ -292,6 +294,7 @@ __global__ void __launch_bounds__(kBlock) matrix_batch_kernel(const MatTile* __r
       for (int k = 0; k < K1; k++) acc[k] = 0;
       Ker::template pack<R>(rec, x, n, f);
       Ker::template pair<R, MODE, true>(acc, d, rec, ctx, K);
+      finish_acc<Ker, R>(acc);
       R* row = M + w.m_off + (((int64_t)s * K0 + k0) * w.nt + t) * K1;
 #pragma unroll
       for (int k = 0; k < K1; k++) row[k] = acc[k] * scale;

@@ -25,6 +25,8 @@
 // and may produce inf/NaN for d = 0 when !MASKED (the evaluator detects that per tile and re-runs the tile masked).  MODE is the
 // accuracy request: 0 >= 7 digits, 1 >= 14 digits, 2 full precision of R.  The context (ctx.v, up to 4 doubles) is the
 // functor's ctx_ptr payload, copied at launch.
+// Optional: `template <class R> static __device__ void finish(R (&acc)[K1])` is applied once to a target's sums before they are written —
+// for a kernel whose pair() fills only part of a symmetric output (ukernels.hpp: Stokes3D_FxT).
 // A kernel with per-launch constants of its own supplies a Consts type instead of DefaultConsts: it is built once per workgroup from
 // (double* lds) or, when it has such a constructor, from (double* lds, const KerCtx& ctx) — e.g. to derive scalar-register constants
 // from a wavenumber (ukernels.hpp: HelmholtzConsts) — and handed to every pair() call.

@@ -200,6 +200,7 @@ __device__ __forceinline__ void lists_item(const ListArgs<R>& a, const ListItem&
 #pragma unroll
   for (int j = 0; j < T; j++) {
     const int tl = SPLIT ? (lane & (P - 1)) : (j * kListWave + lane);
+    finish_acc<Ker, R>(acc[j]);
     if (tl < it.nt && (!SPLIT || rep == 0)) {
       const int64_t t = it.t0 + tl;
 #pragma unroll

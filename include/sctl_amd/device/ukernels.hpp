@@ -128,6 +128,17 @@ template <> struct HelmholtzConsts<double> {         // fp64: table-driven sinco
   }
 };
 
+// A kernel whose pair() leaves some entries of acc to be derived from others — a symmetric output: the traction kernel fills the upper
+// triangle only — supplies `template <class R> static void finish(R (&acc)[K1])`; the evaluators apply it once, when the sums leave
+// the registers (finish_acc).
+template <class Ker, class R, class = void> struct FinishOf {
+  static __device__ __forceinline__ void apply(R (&)[Ker::K1]) {}
+};
+template <class Ker, class R> struct FinishOf<Ker, R, std::void_t<decltype(&Ker::template finish<R>)>> {
+  static __device__ __forceinline__ void apply(R (&acc)[Ker::K1]) { Ker::template finish<R>(acc); }
+};
+template <class Ker, class R> __device__ __forceinline__ void finish_acc(R (&acc)[Ker::K1]) { FinishOf<Ker, R>::apply(acc); }
+
 // Per-kernel constants of a launch: Consts(lds, ctx) when the type takes the context, Consts(lds) otherwise.
 template <class KC> __device__ __forceinline__ KC make_consts(double* lds, const KerCtx& ctx) {
   if constexpr (std::is_constructible<KC, double*, const KerCtx&>::value) return KC(lds, ctx);
@@ -251,11 +262,12 @@ struct Stokes3D_FxT {
     const R rinv = (MODE == 1) ? rsqrt_newton2<MASKED>(len2(d), K.rsq) : rsqrt_masked<MODE, MASKED>(len2(d), K.rsq);   // MODE 1: 2/r
     const R rinv2 = rinv * rinv;
     const R t = dot3(d, rec + 3) * (rinv2 * rinv2 * rinv);
-    for (int j = 0; j < 3; j++) {
+    for (int j = 0; j < 3; j++) {       // u_jk = u_kj: the upper triangle only (6 FMAs instead of 9); finish() fills in the rest
       const R tj = t * d[j];
-      for (int k = 0; k < 3; k++) acc[j * 3 + k] = fma_(tj, d[k], acc[j * 3 + k]);
+      for (int k = j; k < 3; k++) acc[j * 3 + k] = fma_(tj, d[k], acc[j * 3 + k]);
     }
   }
+  template <class R> static __device__ __forceinline__ void finish(R (&acc)[K1]) { acc[3] = acc[1]; acc[6] = acc[2]; acc[7] = acc[5]; }
 };
 
 // ---- Stokeslet + source/sink: u_j = f_j / r + ((r.f) + f_3) r_j / r^3   (kernel_functions.hpp:148-172) ------
