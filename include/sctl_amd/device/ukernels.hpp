@@ -282,7 +282,7 @@ struct Stokes3D_FSxU {
   }
   template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const Consts<R>& K) {
     const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K.rsq);
-    const R t = (dot3(d, rec + 3) + rec[6]) * (rinv * rinv);
+    const R t = fma_(d[2], rec[5], fma_(d[1], rec[4], fma_(d[0], rec[3], rec[6]))) * (rinv * rinv);   // ((r.f) + f_3) / r^2
     for (int j = 0; j < 3; j++) acc[j] = fma_(rinv, fma_(t, d[j], rec[3 + j]), acc[j]);
   }
 };
