@@ -115,12 +115,12 @@ SCTL_AMD_HD double exp_fast(double x, const Coeffs& K) {
 //           sin y = y + y z (s1 + s2 z), cos y - 1 = z (c1 + c2 z), z = y^2 (truncation < 8e-17).  Two-piece reduction
 //           (33-bit head, exact product for |n| < 2^20, i.e. |x| < 1.2e4): the ABSOLUTE error stays ~1e-16, which is what a
 //           kernel value cos + i sin of unit modulus needs; larger arguments take the libm path in the caller.
-//   exp:    nodes 2^(j/64), x = n ln2/64 + r, |r| <= ln2/128, e^r - 1 by a degree-5 polynomial (truncation 3.5e-17 rel).
+//   exp:    nodes 2^(j/256), x = n ln2/256 + r, |r| <= ln2/512, e^r - 1 by a degree-5 polynomial (degree 4 in the folded form below).
 // 16 + 15 fp64 issue slots against 28 + 24 for the table-free code; 14 + 11 for the forms with the wavenumber folded in (below).
-constexpr int kTrigNodes = 512, kExpNodes = 64;
-constexpr int kTableDoubles = 2 * kTrigNodes + kExpNodes;   // [sin_j, cos_j] pairs, then 2^(j/64)
+constexpr int kTrigNodes = 512, kExpShift = 8, kExpNodes = 1 << kExpShift;
+constexpr int kTableDoubles = 2 * kTrigNodes + kExpNodes;   // [sin_j, cos_j] pairs, then 2^(j/256)
 constexpr double kSincosTabMaxArg = 1.2e4;
-constexpr double kExpTabMaxArg = 1.0e6;   // exp_tab_k: the integer part 64 x / ln2 must stay within 31 bits; from |x| = 746 on the result is 0 or inf
+constexpr double kExpTabMaxArg = 1.0e6;   // exp_tab_k: the integer part 256 x / ln2 must stay within 31 bits; from |x| = 746 on the result is 0 or inf
 
 struct TabCoeffs {
   double inv_h, h1, h2, s1, s2, c1, c2, inv_e, e1, e2, p2, p3, p4;
@@ -130,9 +130,9 @@ struct TabCoeffs {
     h2 = -6.07710050650619224932e-11 / 128;               // -(pi/256 - head)
     s1 = -1.66666666666666666667e-01; s2 = 8.33333333333333333333e-03;
     c1 = -0.5; c2 = 4.16666666666666666667e-02;
-    inv_e = 64 * 1.44269504088896338700e+00;              // 64 log2(e)
-    e1 = -6.93147180369123816490e-01 / 64;                // -(ln2/64), head with 32 significant bits
-    e2 = -1.90821492927058770002e-10 / 64;
+    inv_e = kExpNodes * 1.44269504088896338700e+00;       // 256 log2(e)
+    e1 = -6.93147180369123816490e-01 / kExpNodes;         // -(ln2/256), head with 32 significant bits
+    e2 = -1.90821492927058770002e-10 / kExpNodes;
     p2 = 1.66666666666666666667e-01; p3 = 4.16666666666666666667e-02; p4 = 8.33333333333333333333e-03;   // 1/3!, 1/4!, 1/5!
   }
 #ifdef __HIPCC__
@@ -155,7 +155,7 @@ SCTL_AMD_HD void trig_node(int j, double& s, double& c, const Coeffs& K) {
   s = (q & 2) ? -s0 : s0;
   c = ((q + 1) & 2) ? -c0 : c0;
 }
-SCTL_AMD_HD double exp2_node(int j, const Coeffs& K) { return j == 0 ? 1.0 : exp_fast(j * (6.93147180559945309417e-01 / 64), K); }
+SCTL_AMD_HD double exp2_node(int j, const Coeffs& K) { return j == 0 ? 1.0 : exp_fast(j * (6.93147180559945309417e-01 / kExpNodes), K); }
 
 // fill table[kTableDoubles] cooperatively: lane `tid` of `nthreads`
 SCTL_AMD_HD void fill_tables(double* table, int tid, int nthreads, const Coeffs& K) {
@@ -199,19 +199,19 @@ SCTL_AMD_HD double exp_tab_clamped(double xc, const TabCoeffs& K, const double* 
   p = fma_(p, r, K.p2);
   p = fma_(p, r, 0.5);
   const double em1 = fma_(r * r, p, r);
-  return __builtin_ldexp(fma_(t, em1, t), ni >> 6);
+  return __builtin_ldexp(fma_(t, em1, t), ni >> kExpShift);
 }
 
 // ---- the same two functions of x = k r, with the constant k folded into the reduction and the polynomial --------------------------
 // The Helmholtz kernel needs sincos(kr r) and exp(kappa r) for ONE wavenumber per launch and a distance r per pair.  Forming
 // x = k r first costs a multiplication per pair and function; instead the period is divided by k once per launch:
 //   r = n (pi/256)/kr + y,  sin(kr y) = y (kr + z (S1 + S2 z)),  cos(kr y) - 1 = z (C1 + C2 z),  z = y^2,  S1 = -kr^3/6, ...
-//   r = n (ln2/64)/kappa + q,  e^(kappa q) - 1 = q (P1 + q (P2 + q (P3 + q (P4 + q P5)))),  P_m = kappa^m / m!
+//   r = n (ln2/256)/kappa + q,  e^(kappa q) - 1 = q (P1 + q (P2 + q (P3 + q P4))),  P_m = kappa^m / m!   (|kappa q| <= ln2/512: truncation 3.8e-17)
 // (the quotients as two-piece values, so that the reduced argument is as exact as before).  The rounding of x = k r itself
 // disappears; everything else is operation for operation the code above.  k = 0 gives n = 0 and the value at 0.
 struct TabCoeffsK {
   double ih, h1, h2, s0, s1, s2, c1, c2;    // sincos(kr r)
-  double ie, e1, e2, p1, p2, p3, p4, p5;    // exp(kappa r)
+  double ie, e1, e2, p1, p2, p3, p4;        // exp(kappa r)
   // (hi + lo) / d as a two-piece quotient
   static SCTL_AMD_HD void div2(double hi, double lo, double d, double& q1, double& q2) {
     q1 = hi / d;
@@ -226,7 +226,7 @@ struct TabCoeffsK {
     ie = B.inv_e * kappa;
     if (kappa != 0) div2(B.e1, B.e2, kappa, e1, e2); else e1 = e2 = 0;
     const double a2 = kappa * kappa;
-    p1 = kappa; p2 = 0.5 * a2; p3 = B.p2 * a2 * kappa; p4 = B.p3 * a2 * a2; p5 = B.p4 * a2 * a2 * kappa;
+    p1 = kappa; p2 = 0.5 * a2; p3 = B.p2 * a2 * kappa; p4 = B.p3 * a2 * a2;
   }
 #ifdef __HIPCC__
   // the values were computed by vector instructions (the same in every lane): move them to scalar registers first
@@ -235,7 +235,7 @@ struct TabCoeffsK {
   }
   __device__ __forceinline__ void pin() {
     to_sgpr(ih); to_sgpr(h1); to_sgpr(h2); to_sgpr(s0); to_sgpr(s1); to_sgpr(s2); to_sgpr(c1); to_sgpr(c2);
-    to_sgpr(ie); to_sgpr(e1); to_sgpr(e2); to_sgpr(p1); to_sgpr(p2); to_sgpr(p3); to_sgpr(p4); to_sgpr(p5);
+    to_sgpr(ie); to_sgpr(e1); to_sgpr(e2); to_sgpr(p1); to_sgpr(p2); to_sgpr(p3); to_sgpr(p4);
   }
 #endif
 };
@@ -263,11 +263,10 @@ SCTL_AMD_HD double exp_tab_k(double r, const TabCoeffsK& K, const double* table)
   q = fma_(n, K.e2, q);
   const int ni = low_dword(tm);
   const double t = table[2 * kTrigNodes + (ni & (kExpNodes - 1))];
-  double p = fma_(K.p5, q, K.p4);
-  p = fma_(p, q, K.p3);
+  double p = fma_(K.p4, q, K.p3);
   p = fma_(p, q, K.p2);
   p = fma_(p, q, K.p1);
-  return __builtin_ldexp(fma_(t, p * q, t), ni >> 6);
+  return __builtin_ldexp(fma_(t, p * q, t), ni >> kExpShift);
 }
 
 SCTL_AMD_HD double exp_tab(double x, const TabCoeffs& K, const double* table) {
