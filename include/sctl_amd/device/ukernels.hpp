@@ -121,9 +121,16 @@ template <> struct HelmholtzConsts<double> {         // fp64: table-driven sinco
   }
   // the table-driven forms need |Re k| r <= kSincosTabMaxArg and |Im k| r <= kExpTabMaxArg: the speculative pass only tracks the largest
   // distance
-  mutable double rmax = 0;
-  __device__ __forceinline__ void begin_tile() const { rmax = 0; }
+  // (a distance is >= +0 or NaN, so its HIGH WORD orders like the number: the maximum is one 32-bit integer instruction per pair, and a
+  // NaN's high word is larger than any finite one, which sends its tile to the careful pass)
+  mutable unsigned rmax_hi = 0;
+  __device__ __forceinline__ void begin_tile() const { rmax_hi = 0; }
+  __device__ __forceinline__ void note_distance(double r) const {
+    const unsigned h = (unsigned)__double2hiint(r);
+    rmax_hi = (h > rmax_hi) ? h : rmax_hi;
+  }
   __device__ __forceinline__ bool tile_bad(const KerCtx& ctx) const {
+    const double rmax = __hiloint2double((int)(rmax_hi + 1u), 0);   // the next high word up bounds every low word
     return !(__builtin_fabs(ctx.v[0]) * rmax <= fastmath::kSincosTabMaxArg && __builtin_fabs(ctx.v[1]) * rmax <= fastmath::kExpTabMaxArg);
   }
 };
@@ -362,7 +369,7 @@ struct Helmholtz3D_FxU {
   // |Im k| r > 700 is re-run by the careful pass, which branches per pair (libm beyond the table's range).
   template <bool MASKED> static __device__ __forceinline__ void sincos_(double r, const KerCtx& ctx, double& s, double& c, const HelmholtzConsts<double>& K) {
     if (!MASKED) {
-      K.rmax = __builtin_fmax(K.rmax, r);
+      K.note_distance(r);
       fastmath::sincos_tab_k(r, s, c, K.tk, K.table);
       return;
     }
