@@ -160,7 +160,11 @@ Plan make_plan(const KernelEntry& k, int real, int64_t Nt, int64_t Ns) {
   // per lane from Nt = 2^16 up on every kernel (Stokeslet 2^18: 56.2 vs 59.7 ms; traction kernel 72.5 vs 77.9 ms), with
   // the source range split further to keep the chip full; at Nt <= 2^14 one target per lane wins (0.18 vs 0.20 ms).
   (void)k;
+#if defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_T2_FROM)   // A/B builds: the target count from which a lane takes two targets
+  const int t = (Nt >= SCTL_AMD_EXP_T2_FROM) ? 2 : 1;
+#else
   const int t = (Nt >= 32768) ? 2 : 1;
+#endif
   p.t_idx = (t == 1) ? 0 : 1;
   p.wg_x = (Nt + (int64_t)kBlock * t - 1) / ((int64_t)kBlock * t);
   if (p.wg_x < 1) p.wg_x = 1;
