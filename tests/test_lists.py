@@ -168,6 +168,33 @@ def test_hip_lists_random_ragged(O, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", sctl_amd.KERNEL_NAMES)
+def test_hip_lists_every_kernel_every_item_shape(O, name):
+    """Every kernel through the three shapes of a work item — two targets per lane (200 targets), one per lane (50) and lane replicas
+    (5 and 20 targets) — with a box acting on itself; the traction kernel's mirrored output (ukernels.hpp: finish) is checked entry by entry."""
+    rng = np.random.default_rng(77)
+    info = sctl_amd.kernel_info(name)
+    tlen = np.array([200, 50, 5, 20], dtype=np.int64)
+    tstart = np.concatenate([[0], np.cumsum(tlen)[:-1]])
+    Nt, Ns = int(tlen.sum()), 700
+    xt = rng.random(Nt * 3)
+    xs = np.concatenate([xt, rng.random((Ns - Nt) * 3)])      # the first Nt sources ARE the targets (r = 0 pairs in the "self" lists)
+    xn, f = rng.random(Ns * info["nd"]) - 0.5, rng.random(Ns * info["k0"]) - 0.5
+    to, tc, so, sc = [], [], [], []
+    for b in range(4):
+        for s0, n in ((int(tstart[b]), int(tlen[b])), (300, 173), (473, 64), (650, 3)):   # itself, then three other ranges
+            to.append(tstart[b]); tc.append(tlen[b]); so.append(s0); sc.append(n)
+    lists = [np.array(a, dtype=np.int64) for a in (to, tc, so, sc)]
+    ctx = np.array([3.0, 0.2]) if name.startswith("Helmholtz") else None
+    u = sctl_amd.eval_lists_host(name, *lists, xt, xs, xn, f, ctx=ctx)
+    ref = oracle_lists(O, name, lists, xt, xs, xn, f, ctx, u=np.zeros(Nt * info["k1"]))
+    assert rel_l2(u, ref) <= 1e-12, (name, rel_l2(u, ref))
+    if name == "Stokes3D-FxT":
+        m = u.reshape(Nt, 3, 3)
+        assert np.array_equal(m, m.transpose(0, 2, 1)) and np.abs(m - ref.reshape(Nt, 3, 3)).max() <= 1e-12 * np.abs(ref).max()
+
+
+@pytest.mark.gpu
 def test_hip_lists_equal_plain_eval_for_one_list(O):
     """One list covering everything is GenericKernel::Eval: same numbers as the all-pairs entry (to summation order)."""
     rng = np.random.default_rng(9)
