@@ -55,6 +55,22 @@ def cpu_model():
     return "unknown"
 
 
+def physical_cores():
+    """Physical cores this process may run on: distinct (package, core) pairs among the CPUs of its affinity mask (SMT siblings count once)."""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+        seen = set()
+        for c in cpus:
+            base = "/sys/devices/system/cpu/cpu%d/topology/" % c
+            with open(base + "physical_package_id") as fh:
+                pkg = fh.read().strip()
+            with open(base + "core_id") as fh:
+                seen.add((pkg, fh.read().strip()))
+        return len(seen) or len(cpus)
+    except OSError:
+        return os.cpu_count() or 1
+
+
 def cpu_baseline(kernel, N, dtype, budget_s=12.0):
     """The reference's own OpenMP + Vec<> path (oracle/_ref, kind "reference") — or the CPU restatement ("port") when the
     compiled reference is not usable on this host — timed on a bounded target subset against ALL sources."""
@@ -79,7 +95,7 @@ def cpu_baseline(kernel, N, dtype, budget_s=12.0):
     nt = int(min(N, max(nt0, budget_s * rate / N)))
     nt -= nt % 64
     secs = run(nt)
-    return {"value": nt * N / secs, "unit": "pair-interactions/s", "cores": impl.num_threads(), "kind": impl.kind,
+    return {"value": nt * N / secs, "unit": "pair-interactions/s", "cores": min(physical_cores(), impl.num_threads()), "threads": impl.num_threads(), "kind": impl.kind,
             "isa": getattr(impl, "isa", "x86-64-v3"), "cpu": cpu_model(),
             "sample": "%d targets x %d sources (all sources, target subset; work is linear in targets), %.1f s, %s" % (nt, N, secs, kernel)}
 
@@ -186,7 +202,7 @@ def bench_near(args):
                 Fh[e] @ Kb[e]
             reps += 1
         secs = time.perf_counter() - t0
-        line["cpu_baseline"] = {"value": reps * Kb.size / secs, "unit": "matrix-entries/s", "cores": os.cpu_count(), "kind": "port",
+        line["cpu_baseline"] = {"value": reps * Kb.size / secs, "unit": "matrix-entries/s", "cores": physical_cores(), "threads": os.cpu_count(), "kind": "port",
                                 "sample": "%d of %d element blocks, numpy (BLAS) GEMV per block, %d repetitions, %.1f s" % (sample, nelem, reps, secs)}
     print(json.dumps(line), flush=True)
 
@@ -265,7 +281,7 @@ def bench_lists(args):
             list(ex.map(work, chunks))
         secs = time.perf_counter() - t0
         pairs = int((tc[sel] * sc[sel]).sum())
-        line["cpu_baseline"] = {"value": pairs / secs, "unit": "pair-interactions/s", "cores": nthreads, "kind": R.kind,
+        line["cpu_baseline"] = {"value": pairs / secs, "unit": "pair-interactions/s", "cores": min(physical_cores(), nthreads), "threads": nthreads, "kind": R.kind,
                                 "sample": "the %d lists of the first %d target boxes, one GenericKernel::Eval per list from %d worker threads (as PVFMM calls it), %.1f s"
                                           % (sel.size, nb_sample, nthreads, secs)}
     print(json.dumps(line), flush=True)
@@ -307,6 +323,9 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
 
+    # dmabuf IPC is what RCCL needs on this platform; the driver's own `python -m torch.distributed.run ... bench.py` starts the ranks
+    # without going through self_launch(), so the rank path sets it too — before torch (and with it the HIP runtime) is loaded
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     import sctl_amd
@@ -354,7 +373,7 @@ def main():
     # Device time of the evaluation launches, HIP events on the launch stream.  Long steps get an event pair each (the all-gather of a
     # multi-GPU step stays outside it); steps shorter than a few hundred microseconds are bracketed as a whole at N = 1, because two
     # event records per step are themselves a measurable share of such a step.
-    kern_ms = []
+    kern_ms, gather_ms = [], []
     per_step_events = world > 1 or float(N) * float(N) >= 2.0 ** 34
 
     def step(timed):
@@ -364,8 +383,16 @@ def main():
             op.eval_slab(r_trg, r_src, n_src, v_src, out_slab)        # this rank's targets x all sources (HIP kernels)
             e1.record()
             kern_ms.append((e0, e1))
-        else:
-            op.eval_slab(r_trg, r_src, n_src, v_src, out_slab)
+            if world > 1:
+                # the collective leg by its own event pair: all-gather of the slabs (the process group makes the current stream wait
+                # for it) + the Morton -> caller's order copy; on a rank that finished its slab early it also holds the wait for the others
+                e2 = torch.cuda.Event(enable_timing=True)
+                res = op.gather(r_trg, out_slab, out)
+                e2.record()
+                gather_ms.append((e1, e2))
+                return res
+            return out_slab
+        op.eval_slab(r_trg, r_src, n_src, v_src, out_slab)
         return op.gather(r_trg, out_slab, out) if world > 1 else out_slab   # one all-gather, back to the caller's order
 
     def fence():
@@ -392,6 +419,18 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # What every rank measured, and what device it ran on — gathered through the SAME process group the data path uses, so the record
+    # shows how many ranks that communicator really had and that they sat on distinct GPUs (outside the timed region).
+    per_rank = None
+    if world > 1:
+        prop = torch.cuda.get_device_properties(local_rank)
+        mine = {"rank": rank, "local_rank": local_rank, "device": prop.name, "uuid": str(getattr(prop, "uuid", "")),
+                "pci_bus_id": getattr(prop, "pci_bus_id", None), "slab_targets": t1 - t0,
+                "kernel_ms": float(np.mean([a.elapsed_time(b) for a, b in kern_ms])),
+                "gather_ms": float(np.mean([a.elapsed_time(b) for a, b in gather_ms]))}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     ms_per_step = 1e3 * elapsed / args.steps
     pairs_per_step = float(N) * float(N)                 # all ranks together
@@ -423,6 +462,18 @@ def main():
             "sctl_gflops": value * info["flops"] / 1e9,   # the reference's own Profile convention (generic-kernel.txx:188)
             "pct_of_peak_all_gpus": 100.0 * value * fpp / (peak * 1e12 * world),
         }
+        if world > 1:
+            slowest = max(r["kernel_ms"] for r in per_rank)
+            line["collective"] = {
+                "backend": dist.get_backend(), "world_size": dist.get_world_size(), "rehearsal_shared_gpu": rehearsal,
+                "distinct_devices": len({(r["uuid"], r["pci_bus_id"], r["local_rank"]) for r in per_rank}),
+                "op": "all_gather_into_tensor of the potential slabs (%d B per rank) + Morton -> caller's order index copy" % ((t1 - t0) * info["k1"] * out.element_size()),
+                "gather_ms": max(r["gather_ms"] for r in per_rank),          # slowest rank's collective leg, mean over the timed steps
+                "gather_ms_min": min(r["gather_ms"] for r in per_rank),      # the rank that waited least: the collective + copy themselves
+                "per_rank": per_rank}
+            # the same problem on ONE such GPU would take about this long (work is linear in the slab): compare with the N = 1 record
+            line["n1_equiv_ms"] = slowest * world
+            line["kernel_ms_slowest_rank"] = slowest
         if world == 1 and args.digits < 0 and dtype == "f64":
             # Informational, outside the timed region and not part of `value`: the same workload at the accuracy the reference's
             # own callers ask for — ParticleFMM defaults to 10 digits (fmm-wrapper.txx:204), BoundaryIntegralOp to tol 1e-10 (:500).

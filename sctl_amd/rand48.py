@@ -11,6 +11,25 @@ _C = 0xB
 _M = (1 << 48) - 1
 
 
+_BLK = 1 << 16
+_JUMP = None
+
+
+def _jump_tables():
+    """Affine maps of 1.._BLK steps: x_{n+i} = (A_i x_n + C_i) mod 2^48.  uint64 products wrap mod 2^64, which keeps
+    the low 48 bits exact, so the whole block is one vector multiply-add."""
+    global _JUMP
+    if _JUMP is None:
+        ak = np.empty(_BLK, dtype=np.uint64)
+        ck = np.empty(_BLK, dtype=np.uint64)
+        a, c = 1, 0
+        for i in range(_BLK):
+            a, c = (a * _A) & _M, (c * _A + _C) & _M
+            ak[i], ck[i] = a, c
+        _JUMP = (ak, ck)
+    return _JUMP
+
+
 class Rand48:
     def __init__(self, seed=0):
         self.x = ((int(seed) & 0xFFFFFFFF) << 16) | 0x330E
@@ -19,25 +38,17 @@ class Rand48:
         """n successive drand48() values as float64 (exact: 48-bit integers scaled by 2^-48)."""
         out = np.empty(n, dtype=np.float64)
         x = self.x
-        # jump-ahead by blocks: the LCG is affine, so k steps are x -> (A_k x + C_k) mod 2^48
-        blk = 4096
-        if n >= 4 * blk:
-            # per-lane affine maps for offsets 1..blk, then stride over blocks
-            ak = np.empty(blk, dtype=object)
-            ck = np.empty(blk, dtype=object)
-            a, c = 1, 0
-            for i in range(blk):
-                a, c = (a * _A) & _M, (c * _A + _C) & _M
-                ak[i], ck[i] = a, c
+        if n >= 2048:
+            ak, ck = _jump_tables()
+            mask = np.uint64(_M)
             done = 0
-            while n - done >= blk:
-                vals = [(int(ak[i]) * x + int(ck[i])) & _M for i in range(blk)]
-                out[done:done + blk] = np.asarray(vals, dtype=np.float64)
-                x = vals[-1]
-                done += blk
-            for i in range(done, n):
-                x = (_A * x + _C) & _M
-                out[i] = x
+            while done < n:
+                m = min(_BLK, n - done)
+                with np.errstate(over="ignore"):
+                    vals = (ak[:m] * np.uint64(x) + ck[:m]) & mask
+                out[done:done + m] = vals
+                x = int(vals[-1])
+                done += m
         else:
             for i in range(n):
                 x = (_A * x + _C) & _M

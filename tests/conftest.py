@@ -48,6 +48,35 @@ def case_inputs(case, info):
     return xt, xs, xn, f, v0
 
 
+def load_fullsize_manifest():
+    with open(os.path.join(GOLDEN, "fullsize_manifest.json")) as fh:
+        return json.load(fh)
+
+
+_FULL_INPUTS = {}
+
+
+def fullsize_inputs(case, info):
+    """Inputs of a full-size golden case (oracle/gen_golden_fullsize.py): drand48 in the reference driver's order, points in
+    [0,1)^3; the subset's target indices.  Cached per (seed, N, dtype): several cases share one cloud."""
+    from sctl_amd.rand48 import point_cloud
+    dt = np.float32 if case["key"].startswith("cfg4") and case["kind"] != "eval_all" else np.float64
+    key = (case["seed"], case["N"], dt)
+    if key not in _FULL_INPUTS:
+        _FULL_INPUTS.clear()                     # one cloud at a time: the 2^23 case is 235 MB
+        _FULL_INPUTS[key] = point_cloud(case["seed"], case["N"], case["N"], info["k0"], info["nd"], dt, shift=0.0)
+    sel = None
+    if "nsel" in case:
+        sel = case["sel_offset"] + case["sel_stride"] * np.arange(case["nsel"])
+    return _FULL_INPUTS[key] + (sel,)
+
+
+def fullsize_array(key):
+    if "fullsize" not in _NPZ:
+        _NPZ["fullsize"] = np.load(os.path.join(GOLDEN, "fullsize.npz"))
+    return _NPZ["fullsize"][key]
+
+
 def rel_l2(a, b):
     a = np.asarray(a, dtype=np.float64).ravel()
     b = np.asarray(b, dtype=np.float64).ravel()

@@ -48,13 +48,14 @@ def _worker(rank, world, port, Nt, Ns, name, out_dir, compact=True):
     idx = op.slab_indices(t[0]).numpy()               # which targets this rank evaluated: a compact box, or an index range
     box = (xt.reshape(-1, 3)[idx].max(0) - xt.reshape(-1, 3)[idx].min(0)).prod()
     ok = (np.linalg.norm(u.numpy() - ref) <= 1e-14 * np.linalg.norm(ref)) and torch.equal(u, u2) and (t1 - t0) in (Nt // world, Nt // world + 1)
+    ok = ok and (t0, t1) == ((Nt * rank) // world, (Nt * (rank + 1)) // world)      # the reference's rank formula, fmm-wrapper.txx:507
     ok = ok and idx.size == t1 - t0 and ((box < 0.75 or world != 2) if compact else np.array_equal(idx, np.arange(t0, t1)))
     with open(os.path.join(out_dir, "rank%d" % rank), "w") as fh:
         fh.write("ok" if ok else "bad")
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,Nt,compact", [(2, 1000, True), (2, 1001, True), (3, 1000, True), (2, 1001, False)])
+@pytest.mark.parametrize("world,Nt,compact", [(2, 1000, True), (2, 1001, True), (3, 1000, True), (2, 1001, False), (8, 1003, True), (8, 1003, False)])
 def test_sharded_direct_sum_gloo(tmp_path, world, Nt, compact):
     """Slabs cut from the Morton order (default) or by index: the same potential in the caller's order either way."""
     mp.spawn(_worker, args=(world, _free_port(), Nt, 300, "Stokes3D-DxU", str(tmp_path), compact), nprocs=world, join=True)

@@ -147,3 +147,70 @@ def test_bench_self_launches_two_ranks_end_to_end():
     line = _run_bench({"SCTL_AMD_BENCH_REHEARSAL": "1"} if rehearsal else {}, "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline")
     assert line["n_gpus"] == 2 and line["steps"] == 1 and line["value"] > 1e11
     assert line["config"]["n_trg"] == 1 << 20 and line["dtype"] == "f64" and "roofline" in line
+
+
+@pytest.mark.parametrize("workload,kernel,N,dtype", [("helmholtz", "Helmholtz3D-FxU", 1 << 20, "f64"),        # BASELINE configs[4]: 4 GPUs
+                                                     ("laplace_sl_f32", "Laplace3D-FxU", 1 << 23, "f32")])    # configs[3]: the 8-GPU one, 4 ranks here
+def test_bench_multi_rank_record_of_the_other_split_configs(workload, kernel, N, dtype):
+    """BASELINE's two multi-GPU configs through `python bench.py --gpus 4 --workload ...` at their FULL sizes, and the fields that make an
+    N > 1 record prove itself: the backend and world size AS THE PROCESS GROUP REPORTS THEM, one entry per rank with its device and its own
+    kernel / collective times, the collective leg timed by its own event pair, and n1_equiv_ms (slowest rank's kernel time x N).
+    A one-GPU box allows 6 processes on the card (this one included), so config 4's eight ranks are rehearsed as four here (its eight-way
+    slab arithmetic: tests/test_distributed_cpu.py, world 8); with >= 4 GPUs this is a real RCCL run."""
+    import torch
+    rehearsal = torch.cuda.device_count() < 4
+    line = _run_bench({"SCTL_AMD_BENCH_REHEARSAL": "1"} if rehearsal else {}, "--gpus", "4", "--steps", "1", "--warmup", "0", "--workload", workload)
+    assert line["n_gpus"] == 4 and line["config"]["kernel"] == kernel and line["config"]["n_trg"] == N and line["dtype"] == dtype
+    col = line["collective"]
+    assert col["world_size"] == 4 and col["backend"] == ("gloo" if rehearsal else "nccl") and col["rehearsal_shared_gpu"] == rehearsal
+    assert col["distinct_devices"] == (1 if rehearsal else 4)
+    ranks = col["per_rank"]
+    assert [r["rank"] for r in ranks] == [0, 1, 2, 3] and sum(r["slab_targets"] for r in ranks) == N
+    assert all(r["kernel_ms"] > 0 and r["gather_ms"] > 0 for r in ranks)
+    assert line["n1_equiv_ms"] == pytest.approx(4 * max(r["kernel_ms"] for r in ranks))
+    assert "cpu_baseline" not in line and line["roofline"]["kernel_ms"] == pytest.approx(ranks[0]["kernel_ms"])
+    if rehearsal:      # the ranks share one GPU: their kernels run one after the other, so a step takes about the sum of them
+        assert line["ms_per_step"] >= 0.6 * sum(r["kernel_ms"] for r in ranks) / 4
+
+
+def _split_worker(rank, world, port, out_dir):
+    """The two other split configs at reduced size on the shared GPU: sharded result == single-GPU result (Helmholtz with its
+    wavenumber context; fp32 Laplace through the tile-centred path on Morton slabs)."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sctl_amd
+    from sctl_amd.distributed import ShardedDirectSum
+    ok = []
+    g = torch.Generator(device="cuda").manual_seed(3)
+    nt, ns = (1 << 16) + 7, 20011
+    xt = torch.rand(nt * 3, dtype=torch.float64, device="cuda", generator=g)
+    xs = torch.rand(ns * 3, dtype=torch.float64, device="cuda", generator=g)
+    f = torch.rand(ns * 2, dtype=torch.float64, device="cuda", generator=g) - 0.5
+    k = np.array([7.5, 0.3])
+    single = sctl_amd.eval_device("Helmholtz3D-FxU", xt, xs, None, f, ctx=k)
+    u = ShardedDirectSum("Helmholtz3D-FxU", ctx=k).eval(xt, xs, None, f)
+    ok.append(float((u - single).norm() / single.norm()) <= 1e-14)
+    nt, ns = (1 << 20) + 5, 1 << 16
+    xt = torch.rand(nt * 3, dtype=torch.float32, device="cuda", generator=g)
+    xs = torch.rand(ns * 3, dtype=torch.float32, device="cuda", generator=g)
+    f = torch.rand(ns, dtype=torch.float32, device="cuda", generator=g) - 0.5
+    single = sctl_amd.eval_device("Laplace3D-FxU", xt, xs, None, f)
+    u = ShardedDirectSum("Laplace3D-FxU").eval(xt, xs, None, f)
+    ok.append(float((u - single).norm() / single.norm()) <= 2e-6)        # fp32: tile boundaries differ between the slab and the whole set
+    ok.append(sctl_amd.plan("Laplace3D-FxU", 1, nt // world, ns, nt_whole=nt)["path"] == "tile-centred")
+    with open(os.path.join(out_dir, "split%d" % rank), "w") as fh:
+        fh.write(" ".join("ok" if x else "BAD" for x in ok))
+    dist.destroy_process_group()
+
+
+def test_split_of_the_helmholtz_and_fp32_configs_equals_one_gpu(tmp_path):
+    import torch.multiprocessing as mp
+    world = 4
+    mp.spawn(_split_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        res = open(os.path.join(str(tmp_path), "split%d" % r)).read()
+        assert res and "BAD" not in res, (r, res)

@@ -1,10 +1,11 @@
-"""Size-independent properties at BASELINE.json's full sizes (the oracle cannot finish N^2 there): a target subset
-against the oracle with ALL sources, linearity in the density, translation invariance, split-invariance."""
+"""BASELINE.json's five configs at their own sizes.  Config 1 (16384^2) in full against the reference's stored output; the
+others (the oracle cannot finish N^2 there) on a target subset with ALL sources against reference-made fixtures and the
+restatement, plus size-independent properties: linearity in the density, translation invariance, accumulate == sum."""
 import numpy as np
 import pytest
 
 import sctl_amd
-from conftest import ctx_for, rel_l2
+from conftest import ctx_for, fullsize_array, fullsize_inputs, load_fullsize_manifest, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -15,26 +16,73 @@ def _cloud(seed, Nt, Ns, info, dt=np.float64):
             (rng.random(Ns * info["k0"]) - 0.5).astype(dt))
 
 
-@pytest.mark.parametrize("name,N,dt,tol", [
-    ("Laplace3D-FxU", 1 << 20, np.float64, 1e-12),      # BASELINE config 2 size, headline kernel
-    ("Laplace3D-DxU", 1 << 20, np.float64, 1e-12),      # double layer on the tile-centred path at full size
-    ("Laplace3D-FDxUdU", 1 << 20, np.float64, 1e-12),   # config 2 (SL+DL potential+gradient) at its full size
-    ("Stokes3D-FxU", 1 << 18, np.float64, 1e-12),       # config 3
-    ("Helmholtz3D-FxU", 1 << 20, np.float64, 1e-12),    # config 5 (complex wavenumber) at its full size
-    ("Laplace3D-FxU", 1 << 21, np.float32, 1e-4),       # config 4 precision (tolerance vs the f64 oracle)
-    ("Laplace3D-FxU", 1 << 23, np.float32, 1e-4),       # config 4 at its full size (2^23 x 2^23; ~11 s on one GPU)
-])
-def test_full_size_target_subset_against_oracle(O, name, N, dt, tol):
+FULLSIZE = load_fullsize_manifest()["cases"]
+SUBSET_GROUPS = sorted({(c["seed"], c["kernel"]) for c in FULLSIZE if c["kind"].startswith("eval_subset")})
+
+
+@pytest.mark.parametrize("digits", [-1, 10])
+def test_config1_all_targets_against_the_reference(O, digits):
+    """BASELINE config 1 — Laplace3D single layer, 16384 x 16384, fp64, the size the reference's CPU path is quoted on (a
+    src/test-fmm.cpp:6 / fmm-wrapper.txx:35-92 style driver) — through the three entries a caller can take: host buffers
+    (GenericKernel::Eval's replacement), device buffers, and the operator handle ParticleFMM::EvalDirect sits on; every one of
+    the 16384 targets against the REAL reference's stored output (GenericKernel::Eval, and ParticleFMM::EvalDirect at
+    accuracy 10) and against the restatement.  Bar: rel-L2 1e-12 at full precision, 10 * 10^-10 at digits = 10."""
+    import torch
+    name = "Laplace3D-FxU"
+    case = next(c for c in FULLSIZE if c["kind"] == "eval_all" and c["digits"] == digits)
+    info = sctl_amd.kernel_info(name)
+    xt, xs, xn, f, _ = fullsize_inputs(case, info)
+    N = case["N"]
+    assert N == 1 << 14 and xt.size == 3 * N
+    gold = fullsize_array(case["key"])
+    tol = 1e-12 if digits < 0 else 1e-9
+    results = {"eval_host": sctl_amd.eval_host(name, xt, xs, None, f, digits=digits),
+               "eval_device": sctl_amd.eval_device(name, torch.from_numpy(xt).cuda(), torch.from_numpy(xs).cuda(), None, torch.from_numpy(f).cuda(),
+                                                   digits=digits).cpu().numpy()}
+    op = sctl_amd.DirectOp(name, np.float64)
+    op.set_targets(xt)
+    op.set_sources(xs)
+    results["DirectOp"] = op.eval(f, digits=digits)
+    op.close()
+    ref = O.eval(name, xt, xs, None, f)
+    for how, u in results.items():
+        assert u.shape == gold.shape and np.all(np.isfinite(u)), how
+        assert rel_l2(u, gold) <= tol, (how, rel_l2(u, gold))
+        assert rel_l2(u, ref) <= tol, (how, rel_l2(u, ref))
+        if digits == 10:
+            assert rel_l2(u, fullsize_array("cfg1_laplace_sl_16k_fmm10")) <= tol, how
+    # the plan this size takes: the exact kernel with the source range split and the fixed-order reduction (DESIGN.md §4.1)
+    plan = sctl_amd.plan(name, 0, N, N, digits)
+    assert plan["path"] == "exact" and plan["src_splits"] > 1 and plan["trg_per_lane"] == 1, plan
+
+
+@pytest.mark.parametrize("seed,name", SUBSET_GROUPS, ids=lambda v: str(v))
+def test_full_size_target_subset_against_the_reference(O, seed, name):
+    """BASELINE configs 2-5 (+ Laplace SL / DL at 2^20) at their FULL sizes, inputs from drand48: the device result at a fixed
+    512-target subset against (a) the REAL reference's output for those targets and all sources, stored by
+    oracle/gen_golden_fullsize.py, and (b) the restatement.  f64: rel-L2 1e-12 (digits 10: 1e-9).  fp32 (config 4, 2^23 x 2^23,
+    ~10 s on one GPU): 1e-4 against the reference's fp64 result on the same fp32-rounded inputs and against its own fp32
+    result (which itself is 5.5e-5 from fp64)."""
     import torch
     info = sctl_amd.kernel_info(name)
-    xt, xs, xn, f = _cloud(21, N, N, info, dt)
+    cases = [c for c in FULLSIZE if c["seed"] == seed]
+    xt, xs, xn, f, sel = fullsize_inputs(cases[0], info)
+    N = cases[0]["N"]
+    f32 = xt.dtype == np.float32
     d = [torch.from_numpy(a).cuda() for a in (xt, xs, xn, f)]
-    u = sctl_amd.eval_device(name, *d, ctx=ctx_for(name)).cpu().numpy().reshape(N, info["k1"])
-    assert np.all(np.isfinite(u))
-    sel = np.random.default_rng(5).choice(N, 512, replace=False)
-    xt64 = xt.reshape(N, 3)[sel].astype(np.float64).ravel().copy()
-    ref = O.eval(name, xt64, xs.astype(np.float64), xn.astype(np.float64), f.astype(np.float64), ctx=ctx_for(name)).reshape(512, info["k1"])
-    assert rel_l2(u[sel], ref) <= tol, rel_l2(u[sel], ref)
+    ref = O.eval(name, *[a.astype(np.float64) for a in (xt.reshape(N, 3)[sel].ravel(), xs, xn, f)], ctx=ctx_for(name))
+    done = set()
+    for c in cases:
+        if c["digits"] not in done:
+            done.add(c["digits"])
+            u = sctl_amd.eval_device(name, *d, ctx=ctx_for(name), digits=c["digits"]).cpu().numpy().reshape(N, info["k1"])
+            assert np.all(np.isfinite(u))
+            us = u[sel].ravel()
+            tol = 1e-4 if f32 else (1e-9 if c["digits"] == 10 else 1e-12)
+            assert rel_l2(us, ref) <= tol, (c["key"], "oracle", rel_l2(us, ref))
+        gold = fullsize_array(c["key"])
+        assert gold.shape == us.shape
+        assert rel_l2(us, gold) <= tol, (c["key"], "reference", rel_l2(us, gold))
 
 
 def test_linearity_and_translation_invariance_at_scale():
