@@ -57,7 +57,8 @@ enum sctl_amd_status {
   SCTL_AMD_ERR_BAD_ARGUMENT = -2,   /* the size checks of generic-kernel.txx:94-97                                     */
   SCTL_AMD_ERR_NO_DEVICE = -3,      /* no HIP device / bad device index: there is no CPU fallback behind this ABI      */
   SCTL_AMD_ERR_HIP = -4,            /* a HIP runtime call failed; text in sctl_amd_last_error()                        */
-  SCTL_AMD_ERR_BAD_CONTEXT = -5     /* kernel needs a context blob (Helmholtz wavenumber) of another size              */
+  SCTL_AMD_ERR_BAD_CONTEXT = -5,    /* kernel needs a context blob (Helmholtz wavenumber) of another size              */
+  SCTL_AMD_ERR_PEER = -6            /* rank-parallel call: another rank failed, left or never joined; no rank is left waiting */
 };
 
 /* ---- library / registry -------------------------------------------------------------------------------- */
@@ -98,8 +99,9 @@ typedef struct sctl_amd_kernel_desc {
 } sctl_amd_kernel_desc;
 int sctl_amd_register_kernel(const sctl_amd_kernel_desc* desc);
 /* dlopen()s a plugin; its static initialisers (SCTL_AMD_REGISTER_KERNEL in device/kernel_plugin.hpp) register its kernels.
- * Returns the number of kernels the plugin added (>= 0) or a negative error code.  A C++ program may instead simply link the
- * plugin's object file. */
+ * Returns the number of kernels the plugin added, 0 when this very object had been loaded before, or a negative error code —
+ * also when the object loads but every registration in it was refused (ABI mismatch, duplicate name, incomplete table:
+ * sctl_amd_last_error() carries the reason) or it registers nothing.  A C++ program may instead simply link the plugin's object file. */
 int sctl_amd_load_plugin(const char* path);
 
 /* ---- the hot path: GenericKernel::Eval ------------------------------------------------------------------- */

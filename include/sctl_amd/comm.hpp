@@ -6,8 +6,15 @@
 //     rendezvous  MASTER_ADDR (default 127.0.0.1), MASTER_PORT (default 29411)
 //     GPU         SCTL_AMD_LOCAL_RANK | LOCAL_RANK | OMPI_COMM_WORLD_LOCAL_RANK | SLURM_LOCALID (default: rank) modulo the device count
 // (what torchrun, mpirun and srun export), and builds a sctl_amd_comm: a TCP rendezvous plus, when every rank has its own GPU,
-// an RCCL communicator whose all-gathers run GPU to GPU over xGMI (sctl_amd/csrc/comm.hip).  With no such environment World()
-// is Self(): Rank() = 0, Size() = 1, like the reference built without SCTL_HAVE_MPI (comm.txx:198-212).
+// an RCCL communicator whose all-gathers run GPU to GPU over xGMI (sctl_amd/csrc/comm.hip).  MASTER_ADDR may be a dotted
+// address or a host name (`localhost`, a node name).
+// WHEN World() goes rank-parallel: a world size above 1 alone is not enough — independent single-rank tasks started by srun or
+// mpirun also see SLURM_NTASKS / PMI_SIZE > 1 and must not sit in a rendezvous nobody else joins.  It takes
+//     SCTL_AMD_WORLD_SIZE > 1                                   (explicit opt-in; the rendezvous defaults apply), or
+//     a launcher's size variable > 1 AND both MASTER_ADDR and MASTER_PORT in the environment (torchrun exports them; under
+//     mpirun / srun the job script does: that is the opt-in),
+// and SCTL_AMD_COMM=0 always keeps World() == Self().  With no such environment World() is Self(): Rank() = 0, Size() = 1,
+// like the reference built without SCTL_HAVE_MPI (comm.txx:198-212).
 // ParticleFMM::EvalDirect then follows the reference's rank-parallel contract (fmm-wrapper.txx:504-561): every rank passes the
 // sources and targets IT owns and gets the potential at ITS targets from the sources of ALL ranks.
 // Inside one process several GPUs are still driven through DeviceSet (common.hpp); the two do not combine.
@@ -66,8 +73,11 @@ class Comm {
     return fallback;
   }
   static Comm FromEnvironment() {
-    const long size = Env({"SCTL_AMD_WORLD_SIZE", "WORLD_SIZE", "OMPI_COMM_WORLD_SIZE", "PMI_SIZE", "SLURM_NTASKS"}, 1);
+    if (Env({"SCTL_AMD_COMM"}, 1) == 0) return Comm();
+    const long explicit_size = Env({"SCTL_AMD_WORLD_SIZE"}, 0);
+    const long size = explicit_size > 0 ? explicit_size : Env({"WORLD_SIZE", "OMPI_COMM_WORLD_SIZE", "PMI_SIZE", "SLURM_NTASKS"}, 1);
     if (size <= 1) return Comm();
+    if (explicit_size <= 1 && !(std::getenv("MASTER_ADDR") && std::getenv("MASTER_PORT"))) return Comm();   // no rendezvous named: independent tasks
     const long rank = Env({"SCTL_AMD_RANK", "RANK", "OMPI_COMM_WORLD_RANK", "PMI_RANK", "SLURM_PROCID"}, 0);
     const long local = Env({"SCTL_AMD_LOCAL_RANK", "LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "SLURM_LOCALID"}, rank);
     const int ndev = sctl_amd_device_count();

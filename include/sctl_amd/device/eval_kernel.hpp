@@ -69,8 +69,9 @@ __global__ void __launch_bounds__(kBlock) SCTL_AMD_EVAL_ATTR eval_kernel(const E
   const int tid = threadIdx.x;
   const int64_t tbase = (int64_t)blockIdx.x * (kBlock * T);
   using KC = typename Ker::template Consts<R>;
-  __shared__ double kscratch[KC::LDS_DOUBLES > 0 ? KC::LDS_DOUBLES : 1];
-  const KC K = make_consts<KC>(kscratch, a.ctx);
+  constexpr int SCRATCH = AllPairsScratch<KC>::value;   // this evaluator's workgroups are long-lived: a kernel may ask for larger tables here
+  __shared__ double kscratch[SCRATCH > 0 ? SCRATCH : 1];
+  const KC K = make_consts<KC>(kscratch, SCRATCH, a.ctx);
 
   R xt[T][3], acc[T][K1];
 #pragma unroll
@@ -136,7 +137,7 @@ __global__ void __launch_bounds__(kBlock) SCTL_AMD_EVAL_ATTR eval_kernel(const E
     R tacc[T][K1];
     auto run_tile_v = [&](auto masked_tag, auto variant_tag) {
       constexpr bool MASKED = decltype(masked_tag)::value;
-      constexpr bool VARIANT = decltype(variant_tag)::value;
+      constexpr int VARIANT = decltype(variant_tag)::value;
       K.begin_tile();
 #pragma unroll
       for (int j = 0; j < T; j++)
@@ -169,10 +170,18 @@ __global__ void __launch_bounds__(kBlock) SCTL_AMD_EVAL_ATTR eval_kernel(const E
     // a kernel with a launch-uniform special case (Helmholtz: real wavenumber) gets its own straight-line copy of the loop
     auto run_tile = [&](auto masked_tag) {
       if constexpr (KC::HAS_VARIANT) {
-        if (K.variant(a.ctx)) run_tile_v(masked_tag, std::true_type());
-        else run_tile_v(masked_tag, std::false_type());
+        const int v = (int)K.variant(a.ctx);
+        if constexpr (NumVariants<KC>::value > 2) {
+          if (v == 3) run_tile_v(masked_tag, std::integral_constant<int, 3>());
+          else if (v == 2) run_tile_v(masked_tag, std::integral_constant<int, 2>());
+          else if (v == 1) run_tile_v(masked_tag, std::integral_constant<int, 1>());
+          else run_tile_v(masked_tag, std::integral_constant<int, 0>());
+        } else {
+          if (v) run_tile_v(masked_tag, std::integral_constant<int, 1>());
+          else run_tile_v(masked_tag, std::integral_constant<int, 0>());
+        }
       } else {
-        run_tile_v(masked_tag, std::false_type());
+        run_tile_v(masked_tag, std::integral_constant<int, 0>());
       }
     };
     bool repaired = true;

@@ -269,6 +269,171 @@ SCTL_AMD_HD double exp_tab_k(double r, const TabCoeffsK& K, const double* table)
   return __builtin_ldexp(fma_(t, p * q, t), ni >> kExpShift);
 }
 
+// ---- ONE reduction of the distance for the whole factor e^{i k r}, k = kr + i ki (round 3) ---------------------------------------
+// sincos_tab_k and exp_tab_k above reduce the SAME r twice, against two unrelated periods.  With kr > 0 and a decay rate that is small
+// against it (|kappa| <= kr/4, kappa = -Im k: the physically usual case, a slightly absorbing medium) one reduction serves both:
+//     r = n h + y,   h = (2 pi / kr) / 2048,  |y| <= h/2,   n = 2048 m + j   (m whole periods, j the node inside the period)
+//     e^{(kappa + i kr) r} = D_m . T_j . e^{(kappa + i kr) y}
+//     T_j = e^{kappa j h} (cos, sin)(2 pi j / 2048)     2048 complex nodes, the decay inside the period folded INTO the trig table
+//     D_m = e^{kappa m 2 pi / kr}                       one real factor per whole period, kCexpPeriods of them (kr r < 1608)
+//     e^{w} - 1, w = (kappa + i kr) y: |w| <= 1.031 pi/2048 = 1.58e-3, so degree 4 is exact to |w|^5/120 = 8.3e-17; y is REAL, so a Horner
+//     step is two independent real FMAs (real and imaginary coefficient), 8 instructions in all — not the 4-FMA complex multiply-add that
+//     DESIGN.md §4.1 costed in round 2.
+// Per pair: 4 (reduction) + 8 (polynomial) + 4 (T_j (1 + P)) + 1 (D_m into the amplitude) = 17 fp64 instructions and two table reads,
+// against 14 + 10 + 1 for the two separate functions; a real wavenumber needs no D_m and only the even / odd halves: 4 + 5 + 4 = 13
+// against 14.  Tables: 2 x 2048 + 256 doubles = 34 KB of LDS per workgroup.
+constexpr int kCexpShift = 11, kCexpNodes = 1 << kCexpShift, kCexpPeriods = 256;
+constexpr int kCexpTableDoubles = 2 * kCexpNodes + kCexpPeriods;
+constexpr double kCexpMaxPhase = 1600.0;          // kr r below kCexpPeriods whole periods (256 x 2 pi = 1608)
+constexpr double kCexpMaxDecayRatio = 0.25;       // |kappa| <= kr / 4
+
+struct CexpCoeffsK {
+  double ih, h1, h2;                               // 1/h and -h in two pieces
+  double a1r, a1i, a2r, a2i, a3r, a3i, a4r, a4i;   // (kappa + i kr)^m / m!
+  static SCTL_AMD_HD bool usable(double kr, double kappa) { return kr > 0 && __builtin_fabs(kappa) <= kCexpMaxDecayRatio * kr && kr < 1e150 && kr > 1e-150; }
+  SCTL_AMD_HD void set(double kr, double kappa, const TabCoeffs& B) {
+    ih = (4 * B.inv_h) * kr;                       // 2048 / (2 pi) x kr
+    TabCoeffsK::div2(B.h1 / 4, B.h2 / 4, kr, h1, h2);   // -(pi/1024) / kr
+    // powers of c = kappa + i kr
+    const double c2r = kappa * kappa - kr * kr, c2i = 2 * kappa * kr;
+    const double c3r = c2r * kappa - c2i * kr, c3i = c2r * kr + c2i * kappa;
+    const double c4r = c3r * kappa - c3i * kr, c4i = c3r * kr + c3i * kappa;
+    a1r = kappa; a1i = kr;
+    a2r = 0.5 * c2r; a2i = 0.5 * c2i;
+    a3r = B.p2 * c3r; a3i = B.p2 * c3i;            // 1/3!
+    a4r = B.p3 * c4r; a4i = B.p3 * c4i;            // 1/4!
+  }
+#ifdef __HIPCC__
+  __device__ __forceinline__ void pin() {
+    TabCoeffsK::to_sgpr(ih); TabCoeffsK::to_sgpr(h1); TabCoeffsK::to_sgpr(h2);
+    TabCoeffsK::to_sgpr(a1r); TabCoeffsK::to_sgpr(a1i); TabCoeffsK::to_sgpr(a2r); TabCoeffsK::to_sgpr(a2i);
+    TabCoeffsK::to_sgpr(a3r); TabCoeffsK::to_sgpr(a3i); TabCoeffsK::to_sgpr(a4r); TabCoeffsK::to_sgpr(a4i);
+  }
+#endif
+};
+
+// ---- table fill in double-double arithmetic: every entry is the correctly rounded value (0.5 ulp), so the tables add nothing to the
+// per-pair error beyond their own storage rounding.  One-time work per workgroup (8 entries per lane of 256), a fraction of a per cent of it.
+struct DD { double h, l; };
+SCTL_AMD_HD DD dd_norm(double h, double l) { const double s = h + l; return DD{s, l - (s - h)}; }
+SCTL_AMD_HD DD dd_add(DD a, DD b) {
+  const double s = a.h + b.h, bb = s - a.h;
+  const double e = ((a.h - (s - bb)) + (b.h - bb)) + (a.l + b.l);
+  return dd_norm(s, e);
+}
+SCTL_AMD_HD DD dd_neg(DD a) { return DD{-a.h, -a.l}; }
+SCTL_AMD_HD DD dd_mul(DD a, DD b) {
+  const double p = a.h * b.h;
+  const double e = fma_(a.h, b.h, -p) + fma_(a.h, b.l, a.l * b.h);
+  return dd_norm(p, e);
+}
+struct DDC { DD r, i; };
+SCTL_AMD_HD DDC ddc_mul(DDC a, DDC b) { return DDC{dd_add(dd_mul(a.r, b.r), dd_neg(dd_mul(a.i, b.i))), dd_add(dd_mul(a.r, b.i), dd_mul(a.i, b.r))}; }
+SCTL_AMD_HD DDC ddc_pow(DDC a, int n) {          // a^n, n >= 0, by squaring
+  DDC r{DD{1, 0}, DD{0, 0}};
+  while (n) {
+    if (n & 1) r = ddc_mul(r, a);
+    n >>= 1;
+    if (n) a = ddc_mul(a, a);
+  }
+  return r;
+}
+SCTL_AMD_HD DD dd_pow(DD a, int n) {
+  DD r{1, 0};
+  while (n) {
+    if (n & 1) r = dd_mul(r, a);
+    n >>= 1;
+    if (n) a = dd_mul(a, a);
+  }
+  return r;
+}
+// e^x for a small double-double x (|x| < 1e-3): Taylor to x^8 (next term < 3e-30)
+SCTL_AMD_HD DD dd_exp_small(DD x) {
+  const DD f[7] = {DD{2.48015873015873016e-05, 2.15119478667758816e-23}, DD{1.98412698412698413e-04, 1.72095582934207053e-22},
+                   DD{1.38888888888888894e-03, -5.30054395437357706e-20}, DD{8.33333333333333322e-03, 1.15648231731787138e-19},
+                   DD{4.16666666666666644e-02, 2.31296463463574266e-18}, DD{1.66666666666666657e-01, 9.25185853854297066e-18}, DD{0.5, 0}};   // 1/8! .. 1/2!
+  DD p = f[0];
+  for (int k = 1; k < 7; k++) p = dd_add(dd_mul(p, x), f[k]);
+  p = dd_add(dd_mul(p, x), DD{1, 0});
+  return dd_add(dd_mul(p, x), DD{1, 0});
+}
+
+// exp(kappa x) for x = i q with q = q1 + q2 given in two pieces (q1 with <= 33 significant bits, so i q1 is exact for i < 2^19): the product
+// kappa (i q1) is split into its rounded value and the exact remainder, so that the result carries exp_fast's error only
+// (used where the double-double power would leave the double range: the value is then 0, inf or about to be)
+SCTL_AMD_HD double exp_of_multiple(int i, double q1, double q2, double kappa, const Coeffs& K) {
+  const double x1 = i * q1;
+  const double p = kappa * x1;
+  const double lo = fma_(kappa, x1, -p) + kappa * (i * q2);
+  const double e = exp_fast(p, K);
+  return fma_(e, fma_(lo, 0.5 * lo, lo), e);         // e (1 + lo + lo^2 / 2): |lo| < 1e-7
+}
+// the 2048 complex nodes T_j and the period factors D_m, filled cooperatively (lane `tid` of `nthreads`); kr, kappa as in CexpCoeffsK::set.
+// T_1 = e^{kappa h} (cos + i sin)(pi/1024) in double-double (kr h = pi/1024 exactly: the phase step does not depend on k), T_j = T_1^j;
+// D_1 = (e^{kappa h})^2048, D_m = D_1^m.
+SCTL_AMD_HD void fill_cexp_tables(double* table, int tid, int nthreads, double kr, double kappa, const Coeffs& K, const TabCoeffs& B) {
+  double h1, h2;
+  TabCoeffsK::div2(-B.h1 / 4, -B.h2 / 4, kr, h1, h2);          // +h in two pieces
+  const DD x = dd_mul(DD{kappa, 0}, dd_norm(h1, h2));          // kappa h, |x| <= pi/4096
+  const DD eh = dd_exp_small(x);
+  const DDC c1{DD{9.99995293809576191e-01, -1.96680642853221887e-17}, DD{3.06795676296597614e-03, 1.26902790854559250e-19}};   // e^{i pi/1024}
+  const DDC t1{dd_mul(eh, c1.r), dd_mul(eh, c1.i)};
+  if (tid < kCexpNodes) {
+    DDC t = ddc_pow(t1, tid);
+    const DDC step = ddc_pow(t1, nthreads);
+    for (int j = tid; j < kCexpNodes; j += nthreads) {
+      table[2 * j] = t.r.h;
+      table[2 * j + 1] = t.i.h;
+      if (j + nthreads < kCexpNodes) t = ddc_mul(t, step);
+    }
+  }
+  // whole periods: |kappa m 2 pi / kr| stays below ~690 for the double-double power; beyond, the plain exponential (0 / inf in the limit)
+  long long hb;
+  __builtin_memcpy(&hb, &h1, 8);
+  hb &= ~((1ll << 20) - 1);                                    // hh: the leading 33 bits of h1, so that (2048 m) hh (< 2^19 hh) is exact
+  double hh;
+  __builtin_memcpy(&hh, &hb, 8);
+  const double hl = (h1 - hh) + h2;
+  const DD d1 = dd_pow(eh, kCexpNodes);
+  for (int m = tid; m < kCexpPeriods; m += nthreads) {
+    const double est = __builtin_fabs(kappa * (m * (double)kCexpNodes * h1));
+    table[2 * kCexpNodes + m] = (kappa == 0 || m == 0) ? 1.0 : (est < 690.0 ? dd_pow(d1, m).h : exp_of_multiple(m * kCexpNodes, hh, hl, kappa, K));
+  }
+}
+
+// (re, im) of T_j e^{w} and the period factor D_m for a distance r; precondition kr r <= kCexpMaxPhase (indices are masked, so an argument
+// beyond it — or a NaN — reads inside the table and returns garbage that the caller's range check discards)
+SCTL_AMD_HD void cexp_tab_k(double r, double& re, double& im, double& dm, const CexpCoeffsK& K, const double* table) {
+  const double t = fma_(r, K.ih, kRoundMagic);
+  const double n = t - kRoundMagic;
+  double y = fma_(n, K.h1, r);
+  y = fma_(n, K.h2, y);
+  const int ni = low_dword(t);
+  const int j = ni & (kCexpNodes - 1);
+  const double tr = table[2 * j], ti = table[2 * j + 1];
+  dm = table[2 * kCexpNodes + ((ni >> kCexpShift) & (kCexpPeriods - 1))];
+  double pr = fma_(K.a4r, y, K.a3r), pi = fma_(K.a4i, y, K.a3i);
+  pr = fma_(pr, y, K.a2r); pi = fma_(pi, y, K.a2i);
+  pr = fma_(pr, y, K.a1r); pi = fma_(pi, y, K.a1i);
+  pr *= y; pi *= y;                                  // e^w - 1
+  re = fma_(tr, pr, fma_(-ti, pi, tr));
+  im = fma_(ti, pr, fma_(tr, pi, ti));
+}
+// real wavenumber (kappa = 0): e^{i kr y} - 1 = z (a2r + a4r z) + i y (a1i + a3i z), z = y^2; no period factor
+SCTL_AMD_HD void cexp_tab_k_real(double r, double& re, double& im, const CexpCoeffsK& K, const double* table) {
+  const double t = fma_(r, K.ih, kRoundMagic);
+  const double n = t - kRoundMagic;
+  double y = fma_(n, K.h1, r);
+  y = fma_(n, K.h2, y);
+  const int j = low_dword(t) & (kCexpNodes - 1);
+  const double tr = table[2 * j], ti = table[2 * j + 1];
+  const double z = y * y;
+  const double pr = z * fma_(z, K.a4r, K.a2r);
+  const double pi = y * fma_(z, K.a3i, K.a1i);
+  re = fma_(tr, pr, fma_(-ti, pi, tr));
+  im = fma_(ti, pr, fma_(tr, pi, ti));
+}
+
 SCTL_AMD_HD double exp_tab(double x, const TabCoeffs& K, const double* table) {
   const double e = exp_tab_clamped(__builtin_fmin(__builtin_fmax(x, -800.0), 800.0), K, table);
   return (x != x) ? x : e;                  // fmin/fmax drop a NaN: restore it

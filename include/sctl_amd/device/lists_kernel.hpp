@@ -131,7 +131,7 @@ __device__ __forceinline__ void lists_item(const ListArgs<R>& a, const ListItem&
     R tacc[T][K1];
     auto run_tile_v = [&](auto masked_tag, auto variant_tag) {
       constexpr bool MASKED = decltype(masked_tag)::value;
-      constexpr bool VARIANT = decltype(variant_tag)::value;
+      constexpr int VARIANT = decltype(variant_tag)::value;
       K.begin_tile();
 #pragma unroll
       for (int j = 0; j < T; j++)
@@ -167,10 +167,10 @@ __device__ __forceinline__ void lists_item(const ListArgs<R>& a, const ListItem&
     };
     auto run_tile = [&](auto masked_tag) {   // a launch-uniform special case of the kernel (Helmholtz: real wavenumber) has its own loop
       if constexpr (KC::HAS_VARIANT) {
-        if (K.variant(a.ctx)) run_tile_v(masked_tag, std::true_type());
-        else run_tile_v(masked_tag, std::false_type());
+        if (K.variant(a.ctx) & 1) run_tile_v(masked_tag, std::integral_constant<int, 1>());   // (one-wave work items: the small tables, variants 0 / 1 only)
+        else run_tile_v(masked_tag, std::integral_constant<int, 0>());
       } else {
-        run_tile_v(masked_tag, std::false_type());
+        run_tile_v(masked_tag, std::integral_constant<int, 0>());
       }
     };
     bool repaired = true;

@@ -84,7 +84,7 @@ template <int MODE, bool MASKED> __device__ __forceinline__ float rsqrt_masked(f
 // workgroup call it; it may synchronise).
 template <class R> struct DefaultConsts {
   static constexpr int LDS_DOUBLES = 0;
-  static constexpr bool HAS_VARIANT = false;   // true: pair<R, MODE, MASKED, VARIANT> exists and variant(ctx) picks it per launch
+  static constexpr bool HAS_VARIANT = false;   // true: pair<R, MODE, MASKED, VARIANT> exists and variant(ctx) picks it per launch (0 .. NUM_VARIANTS-1, default 2)
   RsqConst<R> rsq;
   __device__ __forceinline__ explicit DefaultConsts(double*) {}
   // hooks of the speculative (unmasked) tile pass of eval_kernel: a kernel whose fast path has a precondition records
@@ -96,31 +96,52 @@ template <class R> struct HelmholtzConsts;
 template <> struct HelmholtzConsts<float> {          // fp32: libm sincosf / expf
   static constexpr int LDS_DOUBLES = 0;
   static constexpr bool HAS_VARIANT = true;
-  __device__ __forceinline__ bool variant(const KerCtx& ctx) const { return ctx.v[1] == 0; }
+  static constexpr int NUM_VARIANTS = 2;
+  __device__ __forceinline__ int variant(const KerCtx& ctx) const { return ctx.v[1] == 0 ? 1 : 0; }
   RsqConst<float> rsq;
   __device__ __forceinline__ explicit HelmholtzConsts(double*) {}
   __device__ __forceinline__ void begin_tile() const {}
   __device__ __forceinline__ bool tile_bad(const KerCtx&) const { return false; }
 };
-template <> struct HelmholtzConsts<double> {         // fp64: table-driven sincos / exp (fastmath.hpp), tables in LDS
+template <> struct HelmholtzConsts<double> {         // fp64: table-driven e^{ikr} (fastmath.hpp), tables in LDS
+  // Two table sets.  The all-pairs evaluator (256-lane workgroups that live for thousands of tiles) offers LDS_DOUBLES_ALL_PAIRS and, when
+  // the wavenumber allows it (Re k > 0, |Im k| <= Re k / 4), runs the ONE-reduction form: 2048 complex nodes with the decay folded in +
+  // 256 period factors (34 KB).  The one-wave evaluators (lists, matrix blocks) keep the small tables (10 KB) of the two-reduction form:
+  // 34 KB per 64 lanes would cost them their occupancy.
   static constexpr int LDS_DOUBLES = fastmath::kTableDoubles;
-  static constexpr bool HAS_VARIANT = true;            // VARIANT = real wavenumber: no exponential
-  __device__ __forceinline__ bool variant(const KerCtx& ctx) const { return ctx.v[1] == 0; }
+  static constexpr int LDS_DOUBLES_ALL_PAIRS = fastmath::kCexpTableDoubles > fastmath::kTableDoubles ? fastmath::kCexpTableDoubles : fastmath::kTableDoubles;
+  static constexpr bool HAS_VARIANT = true;
+  static constexpr int NUM_VARIANTS = 4;               // 0: complex k, two reductions; 1: real k, sincos only; 2: complex k, one reduction; 3: real k, one reduction
+  bool one_reduction;
+  __device__ __forceinline__ int variant(const KerCtx& ctx) const { return (ctx.v[1] == 0 ? 1 : 0) + (one_reduction ? 2 : 0); }
   RsqConst<double> rsq;
   fastmath::TabCoeffsK tk;     // reduction and polynomial constants with the launch's wavenumber folded in: functions of the distance
+  fastmath::CexpCoeffsK ck;    // the same for the one-reduction form
   const double* table;
-  // (a Consts type constructible from (double*, const KerCtx&) is handed the launch's context: make_consts below)
-  __device__ __forceinline__ HelmholtzConsts(double* lds, const KerCtx& ctx) : table(lds) {
+  // (a Consts type constructible from (double*, int, const KerCtx&) is handed the scratch capacity and the launch's context: make_consts below)
+  __device__ __forceinline__ HelmholtzConsts(double* lds, int lds_doubles, const KerCtx& ctx) : table(lds) {
+#ifdef SCTL_AMD_EXP_HELMHOLTZ_TWO_REDUCTIONS       // A/B switch of tools/ (never defined in the shipped library)
+    one_reduction = false;
+#else
+    one_reduction = lds_doubles >= fastmath::kCexpTableDoubles && fastmath::CexpCoeffsK::usable(ctx.v[0], -ctx.v[1]);
+#endif
     {
       const fastmath::Coeffs full;                   // the table-free polynomials, used here only
-      fastmath::fill_tables(lds, (int)threadIdx.x, (int)blockDim.x, full);
+      if (one_reduction) fastmath::fill_cexp_tables(lds, (int)threadIdx.x, (int)blockDim.x, ctx.v[0], -ctx.v[1], full, fastmath::TabCoeffs());
+      else fastmath::fill_tables(lds, (int)threadIdx.x, (int)blockDim.x, full);
     }
     __syncthreads();
-    tk.set(ctx.v[0], -ctx.v[1], fastmath::TabCoeffs());
-    tk.pin();
+    if (one_reduction) {
+      ck.set(ctx.v[0], -ctx.v[1], fastmath::TabCoeffs());
+      ck.pin();
+    } else {
+      tk.set(ctx.v[0], -ctx.v[1], fastmath::TabCoeffs());
+      tk.pin();
+    }
   }
-  // the table-driven forms need |Re k| r <= kSincosTabMaxArg and |Im k| r <= kExpTabMaxArg: the speculative pass only tracks the largest
-  // distance
+  __device__ __forceinline__ HelmholtzConsts(double* lds, const KerCtx& ctx) : HelmholtzConsts(lds, LDS_DOUBLES, ctx) {}
+  // the table-driven forms need |Re k| r <= kSincosTabMaxArg and |Im k| r <= kExpTabMaxArg (one reduction: Re k r <= kCexpMaxPhase): the
+  // speculative pass only tracks the largest distance
   // (a distance is >= +0 or NaN, so its HIGH WORD orders like the number: the maximum is one 32-bit integer instruction per pair, and a
   // NaN's high word is larger than any finite one, which sends its tile to the careful pass)
   mutable unsigned rmax_hi = 0;
@@ -131,6 +152,7 @@ template <> struct HelmholtzConsts<double> {         // fp64: table-driven sinco
   }
   __device__ __forceinline__ bool tile_bad(const KerCtx& ctx) const {
     const double rmax = __hiloint2double((int)(rmax_hi + 1u), 0);   // the next high word up bounds every low word
+    if (one_reduction) return !(ctx.v[0] * rmax <= fastmath::kCexpMaxPhase);
     return !(__builtin_fabs(ctx.v[0]) * rmax <= fastmath::kSincosTabMaxArg && __builtin_fabs(ctx.v[1]) * rmax <= fastmath::kExpTabMaxArg);
   }
 };
@@ -146,11 +168,20 @@ template <class Ker, class R> struct FinishOf<Ker, R, std::void_t<decltype(&Ker:
 };
 template <class Ker, class R> __device__ __forceinline__ void finish_acc(R (&acc)[Ker::K1]) { FinishOf<Ker, R>::apply(acc); }
 
-// Per-kernel constants of a launch: Consts(lds, ctx) when the type takes the context, Consts(lds) otherwise.
-template <class KC> __device__ __forceinline__ KC make_consts(double* lds, const KerCtx& ctx) {
-  if constexpr (std::is_constructible<KC, double*, const KerCtx&>::value) return KC(lds, ctx);
+// Per-kernel constants of a launch: Consts(lds, capacity, ctx) when the type takes the scratch capacity (in doubles) and the context,
+// Consts(lds, ctx) when it takes the context, Consts(lds) otherwise.
+template <class KC> __device__ __forceinline__ KC make_consts(double* lds, int lds_doubles, const KerCtx& ctx) {
+  if constexpr (std::is_constructible<KC, double*, int, const KerCtx&>::value) return KC(lds, lds_doubles, ctx);
+  else if constexpr (std::is_constructible<KC, double*, const KerCtx&>::value) return KC(lds, ctx);
   else return KC(lds);
 }
+template <class KC> __device__ __forceinline__ KC make_consts(double* lds, const KerCtx& ctx) { return make_consts<KC>(lds, KC::LDS_DOUBLES, ctx); }
+// Scratch the all-pairs evaluator offers a kernel: LDS_DOUBLES_ALL_PAIRS when the Consts type names one, LDS_DOUBLES otherwise.
+template <class KC, class = void> struct AllPairsScratch { static constexpr int value = KC::LDS_DOUBLES; };
+template <class KC> struct AllPairsScratch<KC, std::void_t<decltype(KC::LDS_DOUBLES_ALL_PAIRS)>> { static constexpr int value = KC::LDS_DOUBLES_ALL_PAIRS; };
+// Number of launch-uniform variants of pair(): NUM_VARIANTS when named, else 2 for a HAS_VARIANT kernel (pair<R, MODE, MASKED, bool>).
+template <class KC, class = void> struct NumVariants { static constexpr int value = KC::HAS_VARIANT ? 2 : 1; };
+template <class KC> struct NumVariants<KC, std::void_t<decltype(KC::NUM_VARIANTS)>> { static constexpr int value = KC::NUM_VARIANTS; };
 
 template <class R> __device__ __forceinline__ R fma_(R a, R b, R c);
 template <> __device__ __forceinline__ double fma_<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
@@ -163,6 +194,13 @@ template <class R> __device__ __forceinline__ R dot3(const R (&d)[3], const R* v
 // (>= 14 digits), three instructions instead of four.  The factor 2^p goes into the scale applied once per target
 // (Ker::acc_factor): this is the accuracy ParticleFMM (10 digits) and BoundaryIntegralOp (tol 1e-10) ask for by default, so it is
 // the form the reference's own callers run.  With the masked seed y0 = 0 the result is 0, so the r = 0 rule survives.
+// The step always lands low: with d the seed's relative error it returns (2/r)(1 - 3/2 d^2 - ...), measured over 1.3e8 arguments
+// (tools/ubench/rsq_refine_accuracy.hip) mean -1.725e-16, range [-4.27e-15, +2.5e-16].  A one-sided error is a bias, and a bias does not
+// average out over a sum; its mean is folded into acc_factor (newton2_factor(p) for a kernel whose terms carry (2/r)^p), i.e. into the
+// scale applied once per target: no instruction, the per-pair error keeps its width and loses its offset.  (Centring the RANGE instead —
+// a factor 1 + 3/4 d_max^2 — would put the worst case at +-2.1e-15 but move the mean to +1.9e-15: rms 1.9e-15 against 3.0e-16.)
+constexpr double kNewton2MeanErr = -1.725e-16;
+constexpr double newton2_factor(int p) { return (p == 1 ? 2.0 : p == 3 ? 8.0 : 32.0) * (1.0 + p * kNewton2MeanErr); }
 template <bool MASKED, class R> __device__ __forceinline__ R rsqrt_newton2(R r2, const RsqConst<R>& K) {
   const R y = rsqrt_masked<0, MASKED>(r2, K);
   const R a = r2 * y;
@@ -175,7 +213,7 @@ struct Laplace3D_FxU {
   static constexpr const char* NAME = "Laplace3D-FxU";
   template <class R> using Consts = DefaultConsts<R>;
   static constexpr double scale() { return 1 / (4 * kPi); }
-  static constexpr double acc_factor(int mode) { return mode == 1 ? 2 : 1; }   // MODE 1 accumulates f (2/r)
+  static constexpr double acc_factor(int mode) { return mode == 1 ? newton2_factor(1) : 1; }   // MODE 1 accumulates f (2/r)
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0];
   }
@@ -191,7 +229,7 @@ struct Laplace3D_DxU {
   static constexpr const char* NAME = "Laplace3D-DxU";
   template <class R> using Consts = DefaultConsts<R>;
   static constexpr double scale() { return 1 / (4 * kPi); }
-  static constexpr double acc_factor(int mode) { return mode == 1 ? 8 : 1; }   // MODE 1 accumulates (r.n f) (2/r)^3
+  static constexpr double acc_factor(int mode) { return mode == 1 ? newton2_factor(3) : 1; }   // MODE 1 accumulates (r.n f) (2/r)^3
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R* n, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = n[0] * f[0]; rec[4] = n[1] * f[0]; rec[5] = n[2] * f[0];
   }
@@ -208,7 +246,7 @@ struct Laplace3D_FxdU {
   static constexpr const char* NAME = "Laplace3D-FxdU";
   template <class R> using Consts = DefaultConsts<R>;
   static constexpr double scale() { return -1 / (4 * kPi); }
-  static constexpr double acc_factor(int mode) { return mode == 1 ? 8 : 1; }   // MODE 1 accumulates f r (2/r)^3
+  static constexpr double acc_factor(int mode) { return mode == 1 ? newton2_factor(3) : 1; }   // MODE 1 accumulates f r (2/r)^3
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0];
   }
@@ -242,7 +280,7 @@ struct Stokes3D_DxU {
   static constexpr const char* NAME = "Stokes3D-DxU";
   template <class R> using Consts = DefaultConsts<R>;
   static constexpr double scale() { return 3 / (4 * kPi); }
-  static constexpr double acc_factor(int mode) { return mode == 1 ? 32 : 1; }   // MODE 1 accumulates (...) (2/r)^5
+  static constexpr double acc_factor(int mode) { return mode == 1 ? newton2_factor(5) : 1; }   // MODE 1 accumulates (...) (2/r)^5
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R* n, const R* f) {
     for (int k = 0; k < 3; k++) { rec[k] = x[k]; rec[3 + k] = n[k]; rec[6 + k] = f[k]; }
     rec[9] = 0;
@@ -261,7 +299,7 @@ struct Stokes3D_FxT {
   static constexpr const char* NAME = "Stokes3D-FxT";
   template <class R> using Consts = DefaultConsts<R>;
   static constexpr double scale() { return -3 / (4 * kPi); }
-  static constexpr double acc_factor(int mode) { return mode == 1 ? 32 : 1; }   // MODE 1 accumulates (...) (2/r)^5
+  static constexpr double acc_factor(int mode) { return mode == 1 ? newton2_factor(5) : 1; }   // MODE 1 accumulates (...) (2/r)^5
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0]; rec[4] = f[1]; rec[5] = f[2];
   }
@@ -351,10 +389,19 @@ struct Helmholtz3D_FxU {
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0]; rec[4] = f[1]; rec[5] = 0;
   }
-  template <class R, int MODE, bool MASKED, bool REAL_K = false> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx& ctx, const Consts<R>& K) {
+  // VARIANT (launch-uniform, Consts::variant): bit 0 = real wavenumber (no decay factor), bit 1 = the one-reduction form (fp64 all-pairs only)
+  template <class R, int MODE, bool MASKED, int VARIANT = 0> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx& ctx, const Consts<R>& K) {
+    constexpr bool REAL_K = (VARIANT & 1) != 0;
     const R r2 = len2(d);
     const R rinv = rsqrt_masked<MODE, MASKED>(r2, K.rsq);
     const R r = r2 * rinv;
+    if constexpr ((VARIANT & 2) != 0) {
+      R gr, gi;
+      cexp_<MASKED, REAL_K>(r, rinv, ctx, gr, gi, K);
+      acc[0] = fma_(gr, rec[3], fma_(-gi, rec[4], acc[0]));
+      acc[1] = fma_(gi, rec[3], fma_(gr, rec[4], acc[1]));
+      return;
+    }
     R sn, cs;
     sincos_<MASKED>(r, ctx, sn, cs, K);
     R amp = rinv;
@@ -363,6 +410,29 @@ struct Helmholtz3D_FxU {
     acc[0] = fma_(gr, rec[3], fma_(-gi, rec[4], acc[0]));
     acc[1] = fma_(gi, rec[3], fma_(gr, rec[4], acc[1]));
   }
+  // fp64, one reduction of r for the whole factor e^{ikr} (fastmath.hpp: cexp_tab_k); returns G = e^{ikr} / r.  The speculative pass runs it
+  // unconditionally and records the largest distance; the careful pass branches per pair to libm beyond the table's range.
+  template <bool MASKED, bool REAL_K> static __device__ __forceinline__ void cexp_(double r, double rinv, const KerCtx& ctx, double& gr, double& gi, const HelmholtzConsts<double>& K) {
+    if (MASKED && __builtin_expect(!(ctx.v[0] * r <= fastmath::kCexpMaxPhase), 0)) {
+      double s, c;
+      ::sincos(ctx.v[0] * r, &s, &c);
+      const double amp = REAL_K ? rinv : rinv * ::exp(-ctx.v[1] * r);
+      gr = amp * c; gi = amp * s;
+      return;
+    }
+    if (!MASKED) K.note_distance(r);
+    double re, im;
+    if (REAL_K) {
+      fastmath::cexp_tab_k_real(r, re, im, K.ck, K.table);
+      gr = rinv * re; gi = rinv * im;
+    } else {
+      double dm;
+      fastmath::cexp_tab_k(r, re, im, dm, K.ck, K.table);
+      const double amp = rinv * dm;
+      gr = amp * re; gi = amp * im;
+    }
+  }
+  template <bool MASKED, bool REAL_K> static __device__ __forceinline__ void cexp_(float, float, const KerCtx&, float&, float&, const HelmholtzConsts<float>&) {}   // fp32 has no such variant
   // fp64: Cody-Waite reduction to the nearest node of an LDS table + a short polynomial (fastmath.hpp).  The speculative pass
   // (MASKED = false) runs the forms with the wavenumber folded in, unconditionally, as straight-line code, and only records the
   // largest distance (one v_max_f64) for the end-of-tile check; a tile with |Re k| r > 1.2e4 (two thousand wavelengths) or

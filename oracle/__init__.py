@@ -110,6 +110,16 @@ class Reference(_Base):
     def num_threads(self):
         return self.lib.sctl_ref_num_threads()
 
+    def set_devices(self, devices=None, min_pairs_per_device=-1):
+        """Drop-in build only: the GPU list of sctl_dropin.hpp (sctl_amd::Devices()) and its work-per-GPU threshold."""
+        return set_dropin_devices(self.lib, devices, min_pairs_per_device)
+
+    def get_devices(self):
+        buf = (C.c_int * 64)()
+        mp = C.c_longlong()
+        n = self.lib.sctl_ref_dropin_get_devices(buf, 64, C.byref(mp))
+        return list(buf[:max(n, 0)]), mp.value
+
     def eval(self, name, xt, xs, xn, f, v_trg=None, ctx=None, digits=-1, omp=True, nthreads=0):
         dt = xt.dtype
         inf = self.info(name)
@@ -173,6 +183,14 @@ def far_field_restatement(O, name, xt, xn_trg, xs, xn, wts, f, trg_normal_dot_pr
     return u
 
 
+def set_dropin_devices(lib, devices=None, min_pairs_per_device=-1):
+    lib.sctl_ref_dropin_set_devices.argtypes = [C.c_void_p, C.c_int, C.c_longlong]
+    d = np.ascontiguousarray(devices if devices is not None else [], dtype=np.int32)
+    n = lib.sctl_ref_dropin_set_devices(_ptr(d), d.size, min_pairs_per_device)
+    assert n > 0, "not a drop-in build"
+    return n
+
+
 def restatement():
     path = os.path.join(_HERE, "libsctl_oracle.so")
     if not os.path.exists(path):
@@ -220,12 +238,15 @@ def rel_l2(a, b):
 NEAR_INT_ARRAYS = ("elem_nds_cnt", "near_elem_cnt", "K_near_cnt", "near_scatter_index", "near_trg_cnt", "near_trg_dsp")
 
 
-def reference_near(name, xt, xn_trg, xs, xn, wts, f, trg_normal_dot_prod=False, tol=1e-10, nodes_per_elem=4, upsample=1, rad=0.1, free_nodes=0, dropin=False):
+def reference_near(name, xt, xn_trg, xs, xn, wts, f, trg_normal_dot_prod=False, tol=1e-10, nodes_per_elem=4, upsample=1, rad=0.1, free_nodes=0, dropin=False,
+                   dropin_devices=None):
     """The REAL reference's BoundaryIntegralOp on the synthetic PatchElemList of oracle/ref_near_shim.cpp (build container only).
     Returns u_total (ComputePotential), u_near (ComputeNearInterac alone) and the near-operator arrays SetupNear built.
     free_nodes > 0: TWO element lists — the last `free_nodes` nodes form a second, matrix-free list (sctl_ref_boundary_near2)."""
     path = os.path.join(_HERE, "_ref", "libsctl_ref_near_dropin.so" if dropin else "libsctl_ref_near.so")   # dropin: kernels = sctl_amd::HipKernel
     lib = C.CDLL(path)
+    if dropin and dropin_devices is not None:
+        set_dropin_devices(lib, dropin_devices, 0)
     Ns = xs.size // 3
     Nt = 0 if xt is None else xt.size // 3
     NT = Nt if Nt else Ns

@@ -269,4 +269,28 @@ const char* sctl_ref_isa(void) {
 #endif
 }
 
+// Drop-in build only: the GPU list of include/sctl_amd/sctl_dropin.hpp (sctl_amd::Devices(), MinPairsPerDevice()) — set by the tests to
+// run the reference's call sites over several target slabs; returns the list length (get: copies up to cap entries).
+int sctl_ref_dropin_set_devices(const int* devices, int n, long long min_pairs_per_device) {
+#ifdef SCTL_REF_DROPIN
+  if (n > 0) sctl_amd::Devices().assign(devices, devices + n);
+  if (min_pairs_per_device >= 0) sctl_amd::MinPairsPerDevice() = min_pairs_per_device;
+  return (int)sctl_amd::Devices().size();
+#else
+  (void)devices; (void)n; (void)min_pairs_per_device;
+  return -1;
+#endif
+}
+int sctl_ref_dropin_get_devices(int* devices, int cap, long long* min_pairs_per_device) {
+#ifdef SCTL_REF_DROPIN
+  const std::vector<int>& d = sctl_amd::Devices();
+  for (int i = 0; i < cap && i < (int)d.size(); i++) devices[i] = d[i];
+  if (min_pairs_per_device) *min_pairs_per_device = sctl_amd::MinPairsPerDevice();
+  return (int)d.size();
+#else
+  (void)devices; (void)cap; (void)min_pairs_per_device;
+  return -1;
+#endif
+}
+
 }  // extern "C"

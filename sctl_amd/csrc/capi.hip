@@ -553,10 +553,20 @@ int sctl_amd_register_kernel(const sctl_amd_kernel_desc* d) {
 
 int sctl_amd_load_plugin(const char* path) {
   if (!path || !path[0]) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "empty plugin path");
+  if (void* loaded = dlopen(path, RTLD_NOW | RTLD_NOLOAD)) {   // already in the process: its initialisers ran when it was first loaded
+    (void)loaded;
+    return 0;
+  }
   const int before = registry_size();
+  g_err.clear();                     // the plugin's static registration runs on this thread: a refusal leaves its reason here
   void* h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
   if (!h) { const char* e = dlerror(); return fail(SCTL_AMD_ERR_BAD_ARGUMENT, std::string("cannot load kernel plugin: ") + (e ? e : path)); }
-  return registry_size() - before;   // the handle is kept open on purpose: registered launch pointers point into the plugin
+  const int added = registry_size() - before;   // the handle is kept open on purpose: registered launch pointers point into the plugin
+  if (added == 0) dlclose(h);                   // nothing points into it
+  if (added == 0)
+    return fail(SCTL_AMD_ERR_BAD_ARGUMENT, std::string("kernel plugin ") + path + " was loaded but registered no kernel: " +
+                                               (g_err.empty() ? std::string("it contains no SCTL_AMD_REGISTER_KERNEL") : std::string(g_err)));
+  return added;
 }
 const char* sctl_amd_kernel_name(int kernel) {
   const KernelEntry* k = registry(kernel);
@@ -890,12 +900,19 @@ static int op_eval_impl(sctl_amd_op* op, const void* v_src, const void* f_near, 
                         sctl_amd_comm* comm = nullptr, int64_t ns_local = 0) {
   if (!op) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "null handle");
   const KernelEntry& k = *op->k;
-  if (f_near && op->near.empty()) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "no near-field operator attached: call sctl_amd_op_set_near first");
-  if (f_near && op->near_trg_dim != (op->have_trg_normals ? k.k1 / 3 : k.k1))
-    return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "the attached near-field operator has another potential dimension than the far field delivers");
-  if (k.ctx_bytes != 0 && (ctx_bytes != k.ctx_bytes || !ctx))
-    return fail(SCTL_AMD_ERR_BAD_CONTEXT, std::string(k.name) + " needs a context blob of " + std::to_string(k.ctx_bytes) + " bytes");
-  if ((!comm && op->Ns > 0 && !v_src) || (comm && ns_local > 0 && !v_src) || (op->Nt > 0 && !v_trg)) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "null density or potential array");
+  auto check_arguments = [&]() -> int {
+    if (f_near && op->near.empty()) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "no near-field operator attached: call sctl_amd_op_set_near first");
+    if (f_near && op->near_trg_dim != (op->have_trg_normals ? k.k1 / 3 : k.k1))
+      return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "the attached near-field operator has another potential dimension than the far field delivers");
+    if (k.ctx_bytes != 0 && (ctx_bytes != k.ctx_bytes || !ctx))
+      return fail(SCTL_AMD_ERR_BAD_CONTEXT, std::string(k.name) + " needs a context blob of " + std::to_string(k.ctx_bytes) + " bytes");
+    if ((!comm && op->Ns > 0 && !v_src) || (comm && ns_local > 0 && !v_src) || (op->Nt > 0 && !v_trg)) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "null density or potential array");
+    return SCTL_AMD_OK;
+  };
+  // rank-parallel: the ranks agree on their argument checks BEFORE the first collective, so that a rank with a bad argument does not leave
+  // the others waiting inside the gather (they get SCTL_AMD_ERR_PEER)
+  const int arg_rc = comm ? comm_agree(comm, check_arguments(), "sctl_amd_op_eval_dist") : check_arguments();
+  if (arg_rc) return arg_rc;
   const size_t rs = (op->real == SCTL_AMD_F64) ? 8 : 4;
   const int64_t Ns = op->Ns;
   const size_t near_bytes = f_near ? (size_t)op->near_f_len * rs : 0;
@@ -905,9 +922,14 @@ static int op_eval_impl(sctl_amd_op* op, const void* v_src, const void* f_near, 
     if (nt == 0 && !comm) return SCTL_AMD_OK;      // (a rank without targets still takes part in the gather)
     const size_t g = (size_t)(&d - op->devs.data());
     DeviceScope dev_scope_8(d.device);
-    HIP_TRY(dev_scope_8.err);
-    HIP_TRY(grow(&d.f, &d.cap_f, (size_t)Ns * k.k0 * rs));
-    HIP_TRY(grow(&d.v, &d.cap_v, vbytes));
+    auto reserve = [&]() -> int {
+      HIP_TRY(dev_scope_8.err);
+      HIP_TRY(grow(&d.f, &d.cap_f, (size_t)Ns * k.k0 * rs));
+      HIP_TRY(grow(&d.v, &d.cap_v, vbytes));
+      return SCTL_AMD_OK;
+    };
+    const int reserve_rc = comm ? comm_agree(comm, reserve(), "sctl_amd_op_eval_dist") : reserve();
+    if (reserve_rc) return reserve_rc;
     if (comm) {   // every rank's density into d.f, in the rank order the sources were gathered in
       std::vector<int64_t> got;
       const int rc = comm_gather_to_device(comm, v_src, ns_local * k.k0 * (int64_t)rs, &d.f, &d.cap_f, &got, &PinnedBuf::reserve_and_take, &d.stage, d.st);
@@ -985,14 +1007,20 @@ int sctl_amd_op_eval(sctl_amd_op* op, const void* v_src, void* v_trg, int accumu
 
 // ---- rank-parallel form: every rank owns some targets and some sources (ParticleFMM::EvalDirect under MPI, fmm-wrapper.txx:504-561) ----
 int sctl_amd_op_set_sources_dist(sctl_amd_op* op, sctl_amd_comm* comm, int64_t Ns_local, const void* r_src, const void* n_src) {
-  if (!op || !comm || Ns_local < 0 || (Ns_local > 0 && !r_src)) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "bad source arguments");
-  if (op->devs.size() != 1) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "a rank-parallel operator lives on ONE device per rank");
-  if (Ns_local > 0 && op->k->nd > 0 && !n_src) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, std::string(op->k->name) + " needs source normals (n_src is null)");
+  if (!op || !comm) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "null handle or communicator");
   const size_t rs = (op->real == SCTL_AMD_F64) ? 8 : 4;
   OpDevice& d = op->devs[0];
-  op->have_weights = false;
   DeviceScope scope(d.device);
-  HIP_TRY(scope.err);
+  auto check_arguments = [&]() -> int {
+    if (Ns_local < 0 || (Ns_local > 0 && !r_src)) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "bad source arguments");
+    if (op->devs.size() != 1) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "a rank-parallel operator lives on ONE device per rank");
+    if (Ns_local > 0 && op->k->nd > 0 && !n_src) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, std::string(op->k->name) + " needs source normals (n_src is null)");
+    HIP_TRY(scope.err);
+    return SCTL_AMD_OK;
+  };
+  const int arg_rc = comm_agree(comm, check_arguments(), "sctl_amd_op_set_sources_dist");   // all ranks, before the first collective
+  if (arg_rc) return arg_rc;
+  op->have_weights = false;
   std::vector<int64_t> got, gotn;
   int rc = comm_gather_to_device(comm, r_src, Ns_local * 3 * (int64_t)rs, &d.xs, &d.cap_xs, &got, &PinnedBuf::reserve_and_take, &d.stage, d.st);
   if (rc) return rc;
@@ -1010,8 +1038,10 @@ int sctl_amd_op_set_sources_dist(sctl_amd_op* op, sctl_amd_comm* comm, int64_t N
 
 int sctl_amd_op_eval_dist(sctl_amd_op* op, sctl_amd_comm* comm, int64_t Ns_local, const void* v_src_local, void* v_trg, int accumulate, int digits,
                           const void* ctx, int ctx_bytes) {
-  if (!op || !comm || Ns_local < 0) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "null handle or communicator");
-  if (op->devs.size() != 1) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "a rank-parallel operator lives on ONE device per rank");
+  if (!op || !comm) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "null handle or communicator");
+  const int shape_rc = comm_agree(comm, (Ns_local < 0 || op->devs.size() != 1) ? fail(SCTL_AMD_ERR_BAD_ARGUMENT, "a rank-parallel operator lives on ONE device per rank and takes Ns_local >= 0")
+                                                                                : SCTL_AMD_OK, "sctl_amd_op_eval_dist");
+  if (shape_rc) return shape_rc;
   return op_eval_impl(op, v_src_local, nullptr, v_trg, accumulate, digits, ctx, ctx_bytes, comm, Ns_local);
 }
 

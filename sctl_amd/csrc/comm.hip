@@ -11,6 +11,7 @@
 
 #include <arpa/inet.h>
 #include <dlfcn.h>
+#include <netdb.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
 #include <poll.h>
@@ -18,6 +19,8 @@
 #include <unistd.h>
 
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <memory>
 #include <cstring>
 #include <string>
@@ -96,6 +99,9 @@ struct sctl_amd_comm {
 namespace sctl_amd {
 
 // ---- host-side collectives over the rendezvous sockets (a star through rank 0: meant for counts, ids, test-sized data) ---------
+// The largest contribution rank 0 accepts from one peer: the star carries counts, ids and the data of one-GPU rehearsals; a length
+// above this is a corrupt or foreign message, not a request to allocate it.
+constexpr int64_t kMaxStarBytes = int64_t(1) << 34;
 // every rank contributes n bytes; all receives the concatenation in rank order, bytes_of_rank the sizes.  false = a peer went away.
 static bool star_allgatherv(sctl_amd_comm* c, const void* send, int64_t n, std::vector<char>& all, std::vector<int64_t>& bytes_of_rank) {
   bytes_of_rank.assign((size_t)c->size, 0);
@@ -110,7 +116,7 @@ static bool star_allgatherv(sctl_amd_comm* c, const void* send, int64_t n, std::
     bytes_of_rank[0] = n;
     for (int r = 1; r < c->size; r++) {
       int64_t m = 0;
-      if (!recv_all(c->fd[(size_t)r], &m, 8) || m < 0) return false;
+      if (!recv_all(c->fd[(size_t)r], &m, 8) || m < 0 || m > kMaxStarBytes) return false;
       part[(size_t)r].resize((size_t)m);
       if (m && !recv_all(c->fd[(size_t)r], part[(size_t)r].data(), (size_t)m)) return false;
       bytes_of_rank[(size_t)r] = m;
@@ -131,6 +137,25 @@ static bool star_allgatherv(sctl_amd_comm* c, const void* send, int64_t n, std::
   return tot == 0 || recv_all(c->fd[0], all.data(), (size_t)tot);
 }
 
+// Every rank reports the status of what it did LOCALLY before a collective; all ranks return together: the caller's own failure as it is,
+// SCTL_AMD_ERR_PEER when only another rank failed — so no rank enqueues sends or receives towards a rank that has already left the call
+// (which would hang the stream instead of failing).
+int comm_agree(sctl_amd_comm* c, int local_rc, const char* what) {
+  if (!c || c->size == 1) return local_rc;
+  const std::string own = local_rc ? std::string(sctl_amd_last_error()) : std::string();
+  std::vector<char> all;
+  std::vector<int64_t> sizes;
+  const int32_t mine = local_rc;
+  if (!star_allgatherv(c, &mine, 4, all, sizes)) return set_error(SCTL_AMD_ERR_PEER, std::string(what) + ": rank exchange failed, a peer closed its connection");
+  if (local_rc) return set_error(local_rc, own);
+  for (int r = 0; r < c->size; r++) {
+    int32_t v = 0;
+    std::memcpy(&v, all.data() + 4 * (size_t)r, 4);
+    if (v) return set_error(SCTL_AMD_ERR_PEER, std::string(what) + ": rank " + std::to_string(r) + " failed with status " + std::to_string(v) + " before the collective; no rank entered it");
+  }
+  return SCTL_AMD_OK;
+}
+
 // All ranks' host arrays, concatenated in rank order, into a device buffer of the calling rank (grown on demand):
 // RCCL send/recv between the ranks' device buffers when every rank has its own GPU, the rendezvous sockets otherwise.
 // bytes_of_rank receives the sizes.  Enqueued on st; the staging slices must stay untouched until st is synchronised.
@@ -146,34 +171,44 @@ int comm_gather_to_device(sctl_amd_comm* c, const void* local, int64_t nbytes, v
     return e;
   };
   if (!c->nccl) {   // sockets: the concatenation arrives in host memory and is uploaded whole
-    if (!star_allgatherv(c, local, nbytes, tmp, sizes)) return set_error(SCTL_AMD_ERR_HIP, "rank exchange failed: a peer closed its connection");
-    if (tmp.empty()) return SCTL_AMD_OK;
-    hipError_t e = grow(tmp.size());
-    if (e != hipSuccess) return set_error(SCTL_AMD_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
-    char* q = stage_take(stage, tmp.size());
-    if (!q) return set_error(SCTL_AMD_ERR_HIP, "cannot allocate pinned staging memory");
-    std::memcpy(q, tmp.data(), tmp.size());
-    e = hipMemcpyAsync(*dbuf, q, tmp.size(), hipMemcpyHostToDevice, st);
-    return e == hipSuccess ? SCTL_AMD_OK : set_error(SCTL_AMD_ERR_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e));
+    if (!star_allgatherv(c, local, nbytes, tmp, sizes)) return set_error(SCTL_AMD_ERR_PEER, "rank exchange failed: a peer closed its connection");
+    auto upload_all = [&]() -> int {
+      if (tmp.empty()) return SCTL_AMD_OK;
+      hipError_t e = grow(tmp.size());
+      if (e != hipSuccess) return set_error(SCTL_AMD_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+      char* q = stage_take(stage, tmp.size());
+      if (!q) return set_error(SCTL_AMD_ERR_HIP, "cannot allocate pinned staging memory");
+      std::memcpy(q, tmp.data(), tmp.size());
+      e = hipMemcpyAsync(*dbuf, q, tmp.size(), hipMemcpyHostToDevice, st);
+      return e == hipSuccess ? SCTL_AMD_OK : set_error(SCTL_AMD_ERR_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e));
+    };
+    return comm_agree(c, upload_all(), "host all-gather");   // a rank that could not take the data tells the others before they move on
   }
   // RCCL: sizes over the sockets, payload GPU to GPU over xGMI
-  if (!star_allgatherv(c, &nbytes, 8, tmp, sizes)) return set_error(SCTL_AMD_ERR_HIP, "rank exchange failed: a peer closed its connection");
+  if (!star_allgatherv(c, &nbytes, 8, tmp, sizes)) return set_error(SCTL_AMD_ERR_PEER, "rank exchange failed: a peer closed its connection");
   std::vector<int64_t> n((size_t)c->size), off((size_t)c->size + 1, 0);
   for (int r = 0; r < c->size; r++) { std::memcpy(&n[(size_t)r], tmp.data() + 8 * (size_t)r, 8); off[(size_t)r + 1] = off[(size_t)r] + n[(size_t)r]; }
   sizes = n;
   const int64_t total = off[(size_t)c->size];
   if (total == 0) return SCTL_AMD_OK;
-  hipError_t e = grow((size_t)total);
-  if (e != hipSuccess) return set_error(SCTL_AMD_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
-  char* base = (char*)*dbuf;
-  if (nbytes) {
-    char* q = stage_take(stage, (size_t)nbytes);
-    if (!q) return set_error(SCTL_AMD_ERR_HIP, "cannot allocate pinned staging memory");
-    std::memcpy(q, local, (size_t)nbytes);
-    e = hipMemcpyAsync(base + off[(size_t)c->rank], q, (size_t)nbytes, hipMemcpyHostToDevice, st);
-    if (e != hipSuccess) return set_error(SCTL_AMD_ERR_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e));
-  }
-  int rc = c->rccl.GroupStart();
+  // local preparation (buffer, staging, own block up); its status is agreed on BEFORE any rank posts a send or a receive
+  char* base = nullptr;
+  auto prepare = [&]() -> int {
+    hipError_t e = grow((size_t)total);
+    if (e != hipSuccess) return set_error(SCTL_AMD_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+    base = (char*)*dbuf;
+    if (nbytes) {
+      char* q = stage_take(stage, (size_t)nbytes);
+      if (!q) return set_error(SCTL_AMD_ERR_HIP, "cannot allocate pinned staging memory");
+      std::memcpy(q, local, (size_t)nbytes);
+      e = hipMemcpyAsync(base + off[(size_t)c->rank], q, (size_t)nbytes, hipMemcpyHostToDevice, st);
+      if (e != hipSuccess) return set_error(SCTL_AMD_ERR_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e));
+    }
+    return SCTL_AMD_OK;
+  };
+  int rc = comm_agree(c, prepare(), "device all-gather");
+  if (rc) return rc;
+  rc = c->rccl.GroupStart();
   for (int r = 0; r < c->size && rc == 0; r++) {
     if (r == c->rank) continue;
     if (nbytes) rc = c->rccl.Send(base + off[(size_t)c->rank], (size_t)nbytes, kRcclChar, r, c->nccl, st);
@@ -214,26 +249,63 @@ int sctl_amd_comm_create(int rank, int size, const char* master_addr, int master
   }
   if (!master_addr || !master_addr[0]) master_addr = "127.0.0.1";
   if (master_port <= 0 || master_port > 65535) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "bad rendezvous port");
+  // MASTER_ADDR as launchers export it: dotted IPv4 (fast path) or a host name (`localhost`, a node name from scontrol) -> getaddrinfo
   sockaddr_in sa{};
   sa.sin_family = AF_INET;
   sa.sin_port = htons((uint16_t)master_port);
-  if (inet_pton(AF_INET, master_addr, &sa.sin_addr) != 1) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, std::string("rendezvous address must be dotted IPv4, got ") + master_addr);
+  if (inet_pton(AF_INET, master_addr, &sa.sin_addr) != 1) {
+    addrinfo hints{};
+    hints.ai_family = AF_INET;
+    hints.ai_socktype = SOCK_STREAM;
+    addrinfo* res = nullptr;
+    const int gai = getaddrinfo(master_addr, nullptr, &hints, &res);
+    if (gai != 0 || !res) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, std::string("cannot resolve the rendezvous address '") + master_addr + "': " + (gai ? gai_strerror(gai) : "no IPv4 address"));
+    sa.sin_addr = ((const sockaddr_in*)res->ai_addr)->sin_addr;
+    freeaddrinfo(res);
+  }
+  // The hello every rank sends: a magic word, its rank, the world size it believes in and a job token (SCTL_AMD_JOB_TOKEN, else the
+  // launcher's run / job id; 0 when there is none) — rank 0 drops connections that do not belong to this job and keeps listening.
+  struct Hello { uint32_t magic; int32_t rank; int32_t size; uint32_t pad; uint64_t token; };
+  constexpr uint32_t kMagic = 0x5343544cu;   // "SCTL"
+  uint64_t token = 0;
+  for (const char* v : {"SCTL_AMD_JOB_TOKEN", "TORCHELASTIC_RUN_ID", "SLURM_JOB_ID", "PBS_JOBID", "OMPI_MCA_ess_base_jobid"})
+    if (const char* t = std::getenv(v)) {
+      token = 1469598103934665603ull;        // FNV-1a of the text
+      for (const char* q = t; *q; q++) token = (token ^ (unsigned char)*q) * 1099511628211ull;
+      break;
+    }
   const int one = 1;
   if (rank == 0) {
     c->listen_fd = ::socket(AF_INET, SOCK_STREAM, 0);
     if (c->listen_fd < 0) return set_error(SCTL_AMD_ERR_HIP, "socket() failed");
     (void)setsockopt(c->listen_fd, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
-    if (::bind(c->listen_fd, (sockaddr*)&sa, sizeof sa) != 0 || ::listen(c->listen_fd, size) != 0)
-      return set_error(SCTL_AMD_ERR_HIP, std::string("cannot listen on ") + master_addr + ":" + std::to_string(master_port));
+    if (::bind(c->listen_fd, (sockaddr*)&sa, sizeof sa) != 0) {   // the name may resolve to an address that is not an interface of this host (NAT): any interface
+      sockaddr_in any = sa;
+      any.sin_addr.s_addr = htonl(INADDR_ANY);
+      if (::bind(c->listen_fd, (sockaddr*)&any, sizeof any) != 0) return set_error(SCTL_AMD_ERR_HIP, std::string("cannot bind ") + master_addr + ":" + std::to_string(master_port));
+    }
+    if (::listen(c->listen_fd, size) != 0) return set_error(SCTL_AMD_ERR_HIP, std::string("cannot listen on ") + master_addr + ":" + std::to_string(master_port));
     c->fd.assign((size_t)size, -1);
-    for (int k = 1; k < size; k++) {
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(300);
+    for (int joined = 1; joined < size;) {
+      const long long left_ms = std::chrono::duration_cast<std::chrono::milliseconds>(deadline - std::chrono::steady_clock::now()).count();
       pollfd pf{c->listen_fd, POLLIN, 0};
-      if (::poll(&pf, 1, 300 * 1000) <= 0) return set_error(SCTL_AMD_ERR_HIP, "rendezvous: " + std::to_string(size - k) + " rank(s) did not connect within 5 minutes");
+      if (left_ms <= 0 || ::poll(&pf, 1, (int)left_ms) <= 0)
+        return set_error(SCTL_AMD_ERR_PEER, "rendezvous: " + std::to_string(size - joined) + " rank(s) did not connect within 5 minutes");
       const int f = ::accept(c->listen_fd, nullptr, nullptr);
-      int32_t r = -1;
-      if (f < 0 || !recv_all(f, &r, 4) || r < 1 || r >= size || c->fd[(size_t)r] >= 0) { if (f >= 0) ::close(f); return set_error(SCTL_AMD_ERR_HIP, "rendezvous: bad peer"); }
+      if (f < 0) continue;
+      timeval tv{10, 0};                       // a connection that says nothing within 10 s is not one of ours
+      (void)setsockopt(f, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+      Hello h{};
+      if (!recv_all(f, &h, sizeof h) || h.magic != kMagic || h.size != size || h.token != token || h.rank < 1 || h.rank >= size || c->fd[(size_t)h.rank] >= 0) {
+        ::close(f);                            // stray, foreign or duplicate: drop it and keep accepting until the deadline
+        continue;
+      }
+      tv = timeval{0, 0};                      // members may legitimately stay silent for long (they compute between collectives)
+      (void)setsockopt(f, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
       (void)setsockopt(f, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
-      c->fd[(size_t)r] = f;
+      c->fd[(size_t)h.rank] = f;
+      joined++;
     }
   } else {
     int f = -1;
@@ -244,19 +316,23 @@ int sctl_amd_comm_create(int rank, int size, const char* master_addr, int master
       f = -1;
       std::this_thread::sleep_for(std::chrono::milliseconds(100));
     }
-    const int32_t r = rank;
-    if (f < 0 || !send_all(f, &r, 4)) { if (f >= 0) ::close(f); return set_error(SCTL_AMD_ERR_HIP, std::string("cannot reach rank 0 at ") + master_addr + ":" + std::to_string(master_port)); }
+    const Hello h{kMagic, rank, size, 0, token};
+    if (f < 0 || !send_all(f, &h, sizeof h)) { if (f >= 0) ::close(f); return set_error(SCTL_AMD_ERR_PEER, std::string("cannot reach rank 0 at ") + master_addr + ":" + std::to_string(master_port)); }
     (void)setsockopt(f, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
     c->fd.assign(1, f);
   }
-  // Which data path?  RCCL needs one GPU per rank: every rank reports the PCI bus id of its device; all distinct -> RCCL.
-  char bus[64] = {0};
+  // Which data path?  RCCL needs one GPU per rank: every rank reports "<host name>|<PCI bus id of its device>" (the same bus id on two
+  // nodes is two GPUs); all distinct -> RCCL.
+  char bus[160] = {0};
   if (device >= 0 && device < device_count_quiet() && !(flags & SCTL_AMD_COMM_SOCKETS_ONLY)) {
-    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus - 1, device) != hipSuccess) { (void)hipGetLastError(); bus[0] = 0; }
+    char pci[64] = {0}, host[64] = {0};
+    if (hipDeviceGetPCIBusId(pci, (int)sizeof pci - 1, device) != hipSuccess) { (void)hipGetLastError(); pci[0] = 0; }
+    if (gethostname(host, sizeof host - 1) != 0) host[0] = 0;
+    if (pci[0]) std::snprintf(bus, sizeof bus, "%s|%s", host, pci);
   }
   std::vector<char> all;
   std::vector<int64_t> sizes;
-  if (!star_allgatherv(c.get(), bus, (int64_t)sizeof bus, all, sizes)) return set_error(SCTL_AMD_ERR_HIP, "rendezvous: exchange failed");
+  if (!star_allgatherv(c.get(), bus, (int64_t)sizeof bus, all, sizes)) return set_error(SCTL_AMD_ERR_PEER, "rendezvous: exchange failed");
   bool distinct = true;
   for (int a = 0; a < size && distinct; a++) {
     const char* ba = all.data() + (size_t)a * sizeof bus;
@@ -264,13 +340,13 @@ int sctl_amd_comm_create(int rank, int size, const char* master_addr, int master
     for (int b = 0; b < a && distinct; b++) distinct = std::strcmp(ba, all.data() + (size_t)b * sizeof bus) != 0;
   }
   char ok = (distinct && c->rccl.load()) ? 1 : 0;
-  if (!star_allgatherv(c.get(), &ok, 1, all, sizes)) return set_error(SCTL_AMD_ERR_HIP, "rendezvous: exchange failed");
+  if (!star_allgatherv(c.get(), &ok, 1, all, sizes)) return set_error(SCTL_AMD_ERR_PEER, "rendezvous: exchange failed");
   for (char v : all) ok = ok && v;
   if (ok) {
     RcclUniqueId id{};
     if (rank == 0 && c->rccl.GetUniqueId(&id) != 0) std::memset(&id, 0, sizeof id);
     // rank 0's id to everybody (all ranks contribute 128 bytes; block 0 is the one that counts)
-    if (!star_allgatherv(c.get(), &id, (int64_t)sizeof id, all, sizes)) return set_error(SCTL_AMD_ERR_HIP, "rendezvous: exchange failed");
+    if (!star_allgatherv(c.get(), &id, (int64_t)sizeof id, all, sizes)) return set_error(SCTL_AMD_ERR_PEER, "rendezvous: exchange failed");
     std::memcpy(&id, all.data(), sizeof id);
     DeviceScope scope(device);
     if (scope.err != hipSuccess) return set_error(SCTL_AMD_ERR_HIP, "hipSetDevice failed for the rank's device");
@@ -296,7 +372,7 @@ int sctl_amd_comm_allgatherv_host(sctl_amd_comm* c, const void* send, int64_t se
   if (!c || send_bytes < 0 || (send_bytes > 0 && !send)) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "null communicator or bad send buffer");
   std::vector<char> all;
   std::vector<int64_t> sizes;
-  if (!star_allgatherv(c, send, send_bytes, all, sizes)) return set_error(SCTL_AMD_ERR_HIP, "rank exchange failed: a peer closed its connection");
+  if (!star_allgatherv(c, send, send_bytes, all, sizes)) return set_error(SCTL_AMD_ERR_PEER, "rank exchange failed: a peer closed its connection");
   if (bytes_of_rank) std::memcpy(bytes_of_rank, sizes.data(), 8 * (size_t)c->size);
   if ((int64_t)all.size() > recv_capacity) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "receive buffer too small: " + std::to_string(all.size()) + " bytes arrive");
   if (!all.empty()) std::memcpy(recv, all.data(), all.size());
@@ -337,7 +413,7 @@ int sctl_amd_comm_barrier(sctl_amd_comm* c) {
   std::vector<char> all;
   std::vector<int64_t> sizes;
   const char z = 0;
-  return star_allgatherv(c, &z, 1, all, sizes) ? SCTL_AMD_OK : set_error(SCTL_AMD_ERR_HIP, "rank exchange failed: a peer closed its connection");
+  return star_allgatherv(c, &z, 1, all, sizes) ? SCTL_AMD_OK : set_error(SCTL_AMD_ERR_PEER, "rank exchange failed: a peer closed its connection");
 }
 
 }  // extern "C"

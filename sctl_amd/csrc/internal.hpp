@@ -17,6 +17,7 @@ int mode_for(int real, int digits);                // digits -> rsqrt refinement
 KerCtx make_ctx(const KernelEntry& k, const void* ctx);
 int set_error(int code, const std::string& msg);   // records the text for sctl_amd_last_error() on this thread, returns code
 int device_count_quiet();
+int comm_agree(sctl_amd_comm* c, int local_rc, const char* what);   // comm.hip: all ranks learn whether every rank's local step succeeded
 void count_work(int64_t pairs, const KernelEntry& k);   // sctl_amd_counters (generic-kernel.txx:188)
 
 }  // namespace sctl_amd

@@ -65,6 +65,48 @@ int main() {
     }
   }
   printf("k_abs_err_sin %.3e\nk_abs_err_cos %.3e\nk_rel_err_exp %.3e\nk_specials %d\n", ks, kc, ke, (int)k_specials);
+  // ONE reduction for the whole factor e^{(kappa + i kr) r} (cexp_tab_k): error of D_m (re + i im) relative to |e^{(kappa + i kr) r}|, against
+  // 113-bit arithmetic of the exact products; wavenumbers at both ends of the allowed decay ratio, tiny and large kr, kappa of either sign
+  {
+    static double ctab[kCexpTableDoubles];
+    const double ckr[7] = {7.5, 7.5, 0.013, 250.0, 3.2, 1e-9, 40.0}, ckap[7] = {-0.3, 0.0, 0.013 / 4, -62.5, 0.8, 0.0, -1e-3};
+    double ce = 0, cre = 0, two = 0;
+    bool c_specials = true;
+    for (int m = 0; m < 7; m++) {
+      c_specials = c_specials && CexpCoeffsK::usable(ckr[m], ckap[m]);
+      CexpCoeffsK CK;
+      CK.set(ckr[m], ckap[m], T);
+      TabCoeffsK TK;                       // the two-reduction form on the same arguments, for comparison
+      TK.set(ckr[m], ckap[m], T);
+      for (int t = 0; t < 5; t++) fill_cexp_tables(ctab, t, 5, ckr[m], ckap[m], K, T);
+      const double rmax = fmin(kCexpMaxPhase / ckr[m], 1e6);
+      for (int i = 0; i < 400000; i++) {
+        const double u = drand48(), r = ((i % 3 == 0) ? u * u * u : u) * rmax;
+        double re, im, dm;
+        cexp_tab_k(r, re, im, dm, CK, ctab);
+        const __float128 ph = (__float128)ckr[m] * (__float128)r, mag = expq((__float128)ckap[m] * (__float128)r);
+        const __float128 er = (__float128)dm * (__float128)re - mag * cosq(ph), ei = (__float128)dm * (__float128)im - mag * sinq(ph);
+        ce = fmax(ce, (double)(sqrtq(er * er + ei * ei) / mag));
+        {
+          double s2, c2;
+          sincos_tab_k(r, s2, c2, TK, table);
+          const double a2 = exp_tab_k(r, TK, table);
+          const __float128 fr = (__float128)(a2 * c2) - mag * cosq(ph), fi = (__float128)(a2 * s2) - mag * sinq(ph);
+          two = fmax(two, (double)(sqrtq(fr * fr + fi * fi) / mag));
+        }
+        if (ckap[m] == 0) {
+          cexp_tab_k_real(r, re, im, CK, ctab);
+          const __float128 fr = (__float128)re - cosq(ph), fi = (__float128)im - sinq(ph);
+          cre = fmax(cre, (double)sqrtq(fr * fr + fi * fi));
+        }
+      }
+      double re, im, dm;
+      cexp_tab_k(0.0, re, im, dm, CK, ctab);
+      c_specials = c_specials && re == 1.0 && im == 0.0 && dm == 1.0;
+    }
+    c_specials = c_specials && !CexpCoeffsK::usable(0.0, 0.0) && !CexpCoeffsK::usable(-7.5, 0.1) && !CexpCoeffsK::usable(1.0, 0.26) && !CexpCoeffsK::usable(1.0, -0.26);
+    printf("cexp_rel_err %.3e\ncexp_real_abs_err %.3e\ncexp_specials %d\ntwo_reductions_rel_err %.3e\n", ce, cre, (int)c_specials, two);
+  }
   double s1, c1;
   sincos_tab(0.0, s1, c1, T, table);
   const bool tab_specials = exp_tab(-1e9, T, table) == 0.0 && std::isinf(exp_tab(1e9, T, table)) && exp_tab(0.0, T, table) == 1.0 &&

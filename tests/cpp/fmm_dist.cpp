@@ -27,6 +27,7 @@ int main(int argc, char** argv) {
   const Comm comm = Comm::World();
   const int rank = (int)comm.Rank(), np = (int)comm.Size();
   std::printf("rank %d of %d, device %d, transport %s\n", rank, np, comm.Device(), comm.UsesRCCL() ? "rccl" : "sockets");
+  if (hostonly && !comm.Handle()) return 0;   // World() == Self(): nothing to exchange
   if (hostonly) {
     std::vector<double> mine((size_t)(rank + 1) * 3, 100.0 * rank), all((size_t)np * (np + 1) / 2 * 3);
     std::vector<int64_t> bytes((size_t)np);

@@ -24,11 +24,11 @@ def _free_port():
     return p
 
 
-def _launch(exe, world, args, extra_env=None, timeout=300):
+def _launch(exe, world, args, extra_env=None, timeout=300, master_addr="127.0.0.1"):
     port = _free_port()
     procs = []
     for r in range(world):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **(extra_env(r) if extra_env else {}))
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR=master_addr, MASTER_PORT=str(port), **(extra_env(r) if extra_env else {}))
         procs.append(subprocess.Popen([exe] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
     for p in procs:
@@ -48,6 +48,80 @@ def test_comm_world_host_collectives_three_ranks(tmp_path):
     for r, (rc, o, e) in enumerate(outs):
         assert rc == 0, (r, e)
         assert "rank %d of 3" % r in o and "host collectives ok" in o and "transport sockets" in o
+
+
+def test_comm_world_resolves_a_host_name(tmp_path):
+    """MASTER_ADDR as launchers export it — a host name, not only dotted IPv4 (getaddrinfo in sctl_amd_comm_create)."""
+    exe = _build(tmp_path, "fmm_dist")
+    outs = _launch(exe, 2, ["10", str(tmp_path / "x"), "hostonly"], timeout=120, master_addr="localhost")
+    for r, (rc, o, e) in enumerate(outs):
+        assert rc == 0, (r, e)
+        assert "rank %d of 2" % r in o and "host collectives ok" in o
+    outs = _launch(exe, 2, ["10", str(tmp_path / "x"), "hostonly"], timeout=120, master_addr="no-such-host.invalid")
+    assert all(rc != 0 and "cannot resolve the rendezvous address" in e for rc, o, e in outs), outs
+
+
+def test_comm_world_is_self_for_independent_tasks(tmp_path):
+    """A launcher's task count alone (independent single-rank tasks under srun / mpirun) must not start a rendezvous: World() goes
+    rank-parallel only with SCTL_AMD_WORLD_SIZE or with MASTER_ADDR and MASTER_PORT named; SCTL_AMD_COMM=0 switches it off."""
+    exe = _build(tmp_path, "fmm_dist")
+    drop = ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_RANK", "SCTL_AMD_WORLD_SIZE", "SCTL_AMD_RANK")
+    base = {k: v for k, v in os.environ.items() if k not in drop}
+    for extra in ({"SLURM_NTASKS": "4", "SLURM_PROCID": "2"}, {"PMI_SIZE": "8", "PMI_RANK": "5"},
+                  {"WORLD_SIZE": "2", "RANK": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port()), "SCTL_AMD_COMM": "0"}):
+        r = subprocess.run([exe, "10", str(tmp_path / "x"), "hostonly"], env=dict(base, **extra), capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0 and "rank 0 of 1" in r.stdout, (extra, r.stdout, r.stderr)
+
+
+def test_rendezvous_drops_stray_connections_and_keeps_listening():
+    """Rank 0's accept loop: a connection that sends something else than this job's hello, and one that says nothing, are closed and the
+    rendezvous goes on; then the host all-gather works.  (Two ranks as two threads of this process; ctypes releases the GIL in the calls.)"""
+    import ctypes as C
+    import threading
+    import time
+    import sctl_amd
+    L = sctl_amd.lib()
+    L.sctl_amd_comm_create.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.sctl_amd_comm_allgatherv_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    L.sctl_amd_comm_destroy.argtypes = [C.c_void_p]
+    L.sctl_amd_comm_destroy.restype = None
+    port = _free_port()
+    handles, rcs, got = [C.c_void_p(), C.c_void_p()], [None, None], [None, None]
+
+    def rank(r):
+        rcs[r] = L.sctl_amd_comm_create(r, 2, b"localhost", port, -1, 1, C.byref(handles[r]))          # flags = sockets only
+        if rcs[r] == 0:
+            mine = np.full(r + 2, float(r + 1))
+            out = np.zeros(5)
+            sizes = (C.c_int64 * 2)()
+            rcs[r] = L.sctl_amd_comm_allgatherv_host(handles[r], mine.ctypes.data, mine.nbytes, out.ctypes.data, out.nbytes, sizes)
+            got[r] = (out, list(sizes))
+
+    t0 = threading.Thread(target=rank, args=(0,))
+    t0.start()
+    strays = []
+    for payload in (b"GET / HTTP/1.0\r\n\r\n" + b"x" * 32, None):            # a foreign protocol; a silent connection (dropped after its 10 s timeout)
+        for _ in range(100):
+            try:
+                s = socket.create_connection(("127.0.0.1", port), timeout=1)
+                break
+            except OSError:
+                time.sleep(0.05)
+        if payload:
+            s.sendall(payload)
+        strays.append(s)
+    t1 = threading.Thread(target=rank, args=(1,))
+    t1.start()
+    t0.join(60)
+    t1.join(60)
+    assert not t0.is_alive() and not t1.is_alive()
+    assert rcs == [0, 0], (rcs, sctl_amd.last_error())
+    for r in range(2):
+        assert got[r][1] == [16, 24] and np.array_equal(got[r][0], [1, 1, 2, 2, 2])
+    for s in strays:
+        s.close()
+    for h in handles:
+        L.sctl_amd_comm_destroy(h)
 
 
 def _cut(N, r, np_):

@@ -19,3 +19,9 @@ def test_fastmath_against_libm(tmp_path):
     assert v["tab_rel_err_exp"] < 4e-16 and v["tab_specials"] == 1
     # the same with the launch's wavenumber folded into the reduction (what the speculative pass runs): six (Re k, -Im k) pairs incl. 0
     assert v["k_abs_err_sin"] < 4e-16 and v["k_abs_err_cos"] < 4e-16 and v["k_rel_err_exp"] < 4e-16 and v["k_specials"] == 1
+    # round 3: ONE reduction of r for the whole factor e^{ikr} (2048 complex nodes with the decay folded in, degree-4 complex polynomial in a
+    # real argument): |error| / |e^{ikr}| over seven wavenumbers up to the allowed decay ratio |Im k| = Re k / 4, phases up to 1600
+    # (tables filled in double-double arithmetic: correctly rounded entries).  The measure is the MODULUS of the complex error, which for the
+    # two-reduction form — the product of a 2.5e-16 exponential and a 2.9e-16 sine / cosine — is 4.9e-16 on the same arguments: the new
+    # form must not be worse than the one it replaces, and a real wavenumber stays below 3e-16.
+    assert v["cexp_rel_err"] < 5e-16 and v["cexp_rel_err"] <= v["two_reductions_rel_err"] and v["cexp_real_abs_err"] < 3e-16 and v["cexp_specials"] == 1

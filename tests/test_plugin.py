@@ -71,6 +71,22 @@ def test_register_refuses_foreign_or_inconsistent_descriptors(plugin):
     assert L.sctl_amd_load_plugin(b"/nonexistent/libplugin.so") == -2
 
 
+def test_load_plugin_reports_an_object_that_registers_nothing(tmp_path):
+    """A shared object that loads but adds no kernel (no SCTL_AMD_REGISTER_KERNEL in it, or every registration refused) is an ERROR
+    carrying the reason — not a silent 0."""
+    import subprocess
+    src = tmp_path / "empty.c"
+    src.write_text("int sctl_amd_test_nothing_here = 1;\n")
+    so = str(tmp_path / "libempty_plugin.so")
+    subprocess.run(["gcc", "-shared", "-fPIC", str(src), "-o", so], check=True)
+    L = sctl_amd.lib()
+    assert L.sctl_amd_load_plugin(so.encode()) == -2
+    assert b"registered no kernel" in L.sctl_amd_last_error()
+    from sctl_amd.api import SctlAmdError
+    with pytest.raises(SctlAmdError):
+        sctl_amd.load_plugin(so)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", MAN["cases"], ids=lambda c: c["key"])
 def test_plugin_kernel_matches_reference_functor(plugin, case):

@@ -32,6 +32,7 @@ int main() {
   std::uniform_real_distribution<double> U(0.0, 1.0), E(-600, 600);
   double m0 = 0, m1 = 0, m2 = 0, s0 = 0, s1 = 0, s2 = 0, lo1 = 0, hi1 = 0, bias1 = 0, lo0 = 0, hi0 = 0, bias0 = 0;
   double lo0p[2] = {0, 0}, hi0p[2] = {0, 0};   // seed error by exponent parity of the argument
+  double c_lo[3] = {0, 0, 0}, c_hi[3] = {0, 0, 0}, c_sum[3] = {0, 0, 0}, c_sq[3] = {0, 0, 0};   // MODE 1 with its mean folded into the scale, p = 1, 3, 5
   long long cnt = 0;
   for (int r = 0; r < rounds; r++) {
     for (int i = 0; i < n; i++) {
@@ -52,6 +53,11 @@ int main() {
       lo0 = fmin(lo0, e0); hi0 = fmax(hi0, e0);
       { int ex; (void)frexp(x[i], &ex); const int par = ex & 1; lo0p[par] = fmin(lo0p[par], e0); hi0p[par] = fmax(hi0p[par], e0); }
       lo1 = fmin(lo1, e1); hi1 = fmax(hi1, e1);
+      for (int q = 0; q < 3; q++) {   // what a kernel with (2/r)^p terms accumulates, over acc_factor = 2^p (1 + p mean): relative error of the pair's value
+        const int p = 2 * q + 1;
+        const double ec = (double)(powl(1.0L + (long double)e1, p) * (long double)(1 << p) / (long double)newton2_factor(p) - 1.0L);
+        c_lo[q] = fmin(c_lo[q], ec); c_hi[q] = fmax(c_hi[q], ec); c_sum[q] += ec; c_sq[q] += ec * ec;
+      }
       cnt++;
     }
   }
@@ -60,6 +66,9 @@ int main() {
          sqrt(s0 / cnt), bias0 / cnt, lo0, hi0, lo0p[0], hi0p[0], lo0p[1], hi0p[1]);
   printf("MODE 1 Newton (unnormalised):    max rel err %.3e (2^%.2f), rms %.3e, mean %.3e, range [%.3e, %.3e]; 3/2 d_max^2 = %.3e\n", m1, log2(m1), sqrt(s1 / cnt),
          bias1 / cnt, lo1, hi1, 1.5 * m0 * m0);
+  for (int q = 0; q < 3; q++)
+    printf("MODE 1, (2/r)^%d over acc_factor = 2^%d (1 + %d x %.3e):  mean %.3e, rms %.3e, range [%.3e, %.3e]\n", 2 * q + 1, 2 * q + 1, 2 * q + 1, kNewton2MeanErr,
+           c_sum[q] / cnt, sqrt(c_sq[q] / cnt), c_lo[q], c_hi[q]);
   printf("MODE 2 Halley:                   max rel err %.3e (2^%.2f = %.2f ulp), rms %.3e\n", m2, log2(m2), m2 / 1.1102230246251565e-16, sqrt(s2 / cnt));
   return 0;
 }
