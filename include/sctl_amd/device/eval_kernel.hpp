@@ -67,7 +67,16 @@ __global__ void __launch_bounds__(kBlock) SCTL_AMD_EVAL_ATTR eval_kernel(const E
   __shared__ V tile[kTile * NV];
 
   const int tid = threadIdx.x;
-  const int64_t tbase = (int64_t)blockIdx.x * (kBlock * T);
+  // (tile, split) of this workgroup.  Workgroups are dealt to the 8 XCDs round-robin in launch order (x fastest), so with the plain
+  // mapping every XCD's L2 streams every source split.  When the splits come in multiples of 8, XCD k — the workgroups b = k mod 8 —
+  // takes the splits [k S/8, (k+1) S/8) for ALL target tiles: a split then lives in one XCD's L2 (the rule of centered_kernel.hpp).
+  unsigned tile_x = blockIdx.x, split_y = blockIdx.y;
+  if (gridDim.y >= 8 && (gridDim.y & 7) == 0) {
+    const unsigned b = blockIdx.x + gridDim.x * blockIdx.y, spx = gridDim.y >> 3, i = b >> 3;
+    tile_x = i / spx;
+    split_y = (b & 7) * spx + i % spx;
+  }
+  const int64_t tbase = (int64_t)tile_x * (kBlock * T);
   using KC = typename Ker::template Consts<R>;
   constexpr int SCRATCH = AllPairsScratch<KC>::value;   // this evaluator's workgroups are long-lived: a kernel may ask for larger tables here
   __shared__ double kscratch[SCRATCH > 0 ? SCRATCH : 1];
@@ -84,7 +93,7 @@ __global__ void __launch_bounds__(kBlock) SCTL_AMD_EVAL_ATTR eval_kernel(const E
     for (int k = 0; k < K1; k++) acc[j][k] = 0;
   }
 
-  const int64_t s_begin = (int64_t)blockIdx.y * a.chunk;
+  const int64_t s_begin = (int64_t)split_y * a.chunk;
   const int64_t s_end = (s_begin + a.chunk < a.Ns) ? s_begin + a.chunk : a.Ns;
   const int64_t len = (s_end > s_begin) ? s_end - s_begin : 0;
   const int ntile = (int)((len + kTile - 1) / kTile);
@@ -211,7 +220,7 @@ __global__ void __launch_bounds__(kBlock) SCTL_AMD_EVAL_ATTR eval_kernel(const E
 #pragma unroll
         for (int k = 0; k < K1; k++) a.v_trg[t * K1 + k] += acc[j][k] * a.scale;   // generic-kernel.txx:184
       } else {
-        R* p = a.partial + ((int64_t)blockIdx.y * a.Nt + t) * K1;
+        R* p = a.partial + ((int64_t)split_y * a.Nt + t) * K1;
 #pragma unroll
         for (int k = 0; k < K1; k++) p[k] = acc[j][k];
       }

@@ -173,6 +173,15 @@ Plan make_plan(const KernelEntry& k, int real, int64_t Nt, int64_t Ns) {
   if (s > ntile) s = ntile;
   if (s > 1024) s = 1024;
   if (s < 1) s = 1;
+#if defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_L2_SPLITS)   // A/B build (tools/ab_eval_l2_splits.sh): one split's source data <= 2 MB, splits in multiples of 8
+  {
+    const int64_t src_bytes = Ns * (3 + k.nd + k.k0) * (real == SCTL_AMD_F64 ? 8 : 4);
+    int64_t s2 = (src_bytes + (2 << 20) - 1) / (2 << 20);
+    if (s2 > s) s = s2;
+    if (s >= 5) s = (s + 7) / 8 * 8;
+    if (s > ntile) s = ntile;
+  }
+#endif
   int64_t tiles_per = (ntile + s - 1) / s;
   if (tiles_per < 1) tiles_per = 1;
   p.chunk = tiles_per * kTile;

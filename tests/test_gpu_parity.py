@@ -247,7 +247,10 @@ def test_reused_host_buffers_are_always_re_read(O):
     op.close()
 
 
-@pytest.mark.parametrize("k", [(7.5, 0.0), (40.0, 0.3), (3.0, 60.0), (5.0, -2.0), (3.0e4, 0.0), (2.0e4, 1.0), (0.0, 4.0), (-12.0, 0.5)],
+@pytest.mark.parametrize("k", [(7.5, 0.0), (40.0, 0.3), (3.0, 60.0), (5.0, -2.0), (3.0e4, 0.0), (2.0e4, 1.0), (0.0, 4.0), (-12.0, 0.5),
+                               # round 3, the one-reduction form (Re k > 0, |Im k| <= Re k / 4): both ends of the decay ratio, just outside it (the
+                               # two-reduction form), and 248 whole periods across the cloud (the last entries of the period-factor table)
+                               (40.0, 10.0), (40.0, -10.0), (40.0, 10.5), (900.0, 5.0), (1e-3, 2e-4)],
                          ids=lambda k: "k=%g%+gi" % k)
 @pytest.mark.parametrize("shape", [(700, 900), (5000, 6000)], ids=lambda s: "%dx%d" % s)
 def test_helmholtz_wavenumbers(O, k, shape):

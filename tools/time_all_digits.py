@@ -16,7 +16,13 @@ def run(name, N, digits, reps=3):
     for _ in range(reps): sctl_amd.eval_device(name, xt, xs, xn, f, v_trg=v, ctx=ctx, digits=digits)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)/reps
-    return ms, N*N/(ms*1e-3)*sctl_amd.flops_per_pair(name)/78.6e12*100
+    return ms, N*N/(ms*1e-3)*executed_flops(name)/78.6e12*100
+def executed_flops(name):
+    """Flops per pair the fraction is taken against.  SURVEY §8d's convention is 3 + FLOPS() + 2 K0 K1; the traction kernel's 3 x 9 output is
+    symmetric in its last two indices and the device kernel accumulates the six upper entries only (ukernels.hpp: Stokes3D_FxT, finish()
+    mirrors them), so its executed count is 3 + 39 + 2*3*6 = 78, not 96 — a fraction of the chip's peak must be taken against work the chip did."""
+    return 78 if name == "Stokes3D-FxT" else sctl_amd.flops_per_pair(name)
 for k in sctl_amd.KERNEL_NAMES:
     a, b = run(k, 1 << 18, -1), run(k, 1 << 18, 10)
-    print("%-18s 2^18 x 2^18 fp64: full precision %8.2f ms %5.1f %% of peak | 10 digits %8.2f ms %5.1f %% of peak (%+.1f %%)" % (k, a[0], a[1], b[0], b[1], 100 * (a[0] / b[0] - 1)), flush=True)
+    note = "   [against the 78 flops/pair executed (symmetric output: 6 of 9 entries accumulated); by the 96 of the 3 + FLOPS() + 2 K0 K1 convention the same times read %.1f / %.1f]" % (a[1] * 96 / 78, b[1] * 96 / 78) if k == "Stokes3D-FxT" else ""
+    print("%-18s 2^18 x 2^18 fp64: full precision %8.2f ms %5.1f %% of peak | 10 digits %8.2f ms %5.1f %% of peak (%+.1f %%)%s" % (k, a[0], a[1], b[0], b[1], 100 * (a[0] / b[0] - 1), note), flush=True)
