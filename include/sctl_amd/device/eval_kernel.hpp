@@ -69,12 +69,14 @@ __global__ void __launch_bounds__(kBlock) SCTL_AMD_EVAL_ATTR eval_kernel(const E
   const int tid = threadIdx.x;
   // (tile, split) of this workgroup.  Workgroups are dealt to the 8 XCDs round-robin in launch order (x fastest), so with the plain
   // mapping every XCD's L2 streams every source split.  When the splits come in multiples of 8, XCD k — the workgroups b = k mod 8 —
-  // takes the splits [k S/8, (k+1) S/8) for ALL target tiles: a split then lives in one XCD's L2 (the rule of centered_kernel.hpp).
+  // takes the splits [k S/8, (k+1) S/8), ONE AT A TIME: all target tiles against its first split, then all against the next.  A split
+  // (<= 2 MB by the planner's rule) then lives in one XCD's 4 MB L2 while that XCD's workgroups go through the tiles.  (Tile-major
+  // order inside an XCD keeps S/8 splits hot at once: 4 x 2 MB measured 87 % L2 hits on the sources where this order has them all.)
   unsigned tile_x = blockIdx.x, split_y = blockIdx.y;
   if (gridDim.y >= 8 && (gridDim.y & 7) == 0) {
-    const unsigned b = blockIdx.x + gridDim.x * blockIdx.y, spx = gridDim.y >> 3, i = b >> 3;
-    tile_x = i / spx;
-    split_y = (b & 7) * spx + i % spx;
+    const unsigned b = blockIdx.x + gridDim.x * blockIdx.y, i = b >> 3;
+    tile_x = i % gridDim.x;
+    split_y = (b & 7) * (gridDim.y >> 3) + i / gridDim.x;
   }
   const int64_t tbase = (int64_t)tile_x * (kBlock * T);
   using KC = typename Ker::template Consts<R>;

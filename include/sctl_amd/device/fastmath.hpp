@@ -214,7 +214,7 @@ struct TabCoeffsK {
   double ie, e1, e2, p1, p2, p3, p4;        // exp(kappa r)
   // (hi + lo) / d as a two-piece quotient
   static SCTL_AMD_HD void div2(double hi, double lo, double d, double& q1, double& q2) {
-    q1 = hi / d;
+    q1 = hi / d;   // (an explicit FMA below: contraction cannot change it)
     q2 = (fma_(-q1, d, hi) + lo) / d;
   }
   SCTL_AMD_HD void set(double kr, double kappa, const TabCoeffs& B) {
@@ -314,15 +314,25 @@ struct CexpCoeffsK {
 
 // ---- table fill in double-double arithmetic: every entry is the correctly rounded value (0.5 ulp), so the tables add nothing to the
 // per-pair error beyond their own storage rounding.  One-time work per workgroup (8 entries per lane of 256), a fraction of a per cent of it.
+// NO floating-point contraction in this block: hipcc contracts a * b + c into an FMA ACROSS statements by default (-ffp-contract=fast), which
+// turns `p = a.h * b.h; ... s = p + e` into s = fma(a.h, b.h, e) and breaks the error-free transformations (measured on the device before
+// this pragma: table entries off by j x 2.7e-17, i.e. 5.5e-14 at the last node, where the host build of the same code had 1e-16).
+#if defined(__clang__)
+#define SCTL_AMD_FP_EXACT _Pragma("clang fp contract(off)")
+#else
+#define SCTL_AMD_FP_EXACT          // g++ (host tests): built with -ffp-contract=off
+#endif
 struct DD { double h, l; };
-SCTL_AMD_HD DD dd_norm(double h, double l) { const double s = h + l; return DD{s, l - (s - h)}; }
+SCTL_AMD_HD DD dd_norm(double h, double l) { SCTL_AMD_FP_EXACT const double s = h + l; return DD{s, l - (s - h)}; }
 SCTL_AMD_HD DD dd_add(DD a, DD b) {
+  SCTL_AMD_FP_EXACT
   const double s = a.h + b.h, bb = s - a.h;
   const double e = ((a.h - (s - bb)) + (b.h - bb)) + (a.l + b.l);
   return dd_norm(s, e);
 }
 SCTL_AMD_HD DD dd_neg(DD a) { return DD{-a.h, -a.l}; }
 SCTL_AMD_HD DD dd_mul(DD a, DD b) {
+  SCTL_AMD_FP_EXACT
   const double p = a.h * b.h;
   const double e = fma_(a.h, b.h, -p) + fma_(a.h, b.l, a.l * b.h);
   return dd_norm(p, e);
@@ -362,6 +372,7 @@ SCTL_AMD_HD DD dd_exp_small(DD x) {
 // kappa (i q1) is split into its rounded value and the exact remainder, so that the result carries exp_fast's error only
 // (used where the double-double power would leave the double range: the value is then 0, inf or about to be)
 SCTL_AMD_HD double exp_of_multiple(int i, double q1, double q2, double kappa, const Coeffs& K) {
+  SCTL_AMD_FP_EXACT
   const double x1 = i * q1;
   const double p = kappa * x1;
   const double lo = fma_(kappa, x1, -p) + kappa * (i * q2);

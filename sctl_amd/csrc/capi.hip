@@ -173,12 +173,21 @@ Plan make_plan(const KernelEntry& k, int real, int64_t Nt, int64_t Ns) {
   if (s > ntile) s = ntile;
   if (s > 1024) s = 1024;
   if (s < 1) s = 1;
-#if defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_L2_SPLITS)   // A/B build (tools/ab_eval_l2_splits.sh): one split's source data <= 2 MB, splits in multiples of 8
-  {
-    const int64_t src_bytes = Ns * (3 + k.nd + k.k0) * (real == SCTL_AMD_F64 ? 8 : 4);
+  // Splits sized for the L2, in eights (round 3; A/B on one box, profiles/r03_ab_eval_l2_splits.txt): large problems used to get ONE split
+  // and exactly one round of workgroups (2^20 targets, two per lane: 2048 workgroups = 8 per CU), every XCD streaming the whole source set
+  // past its 4 MB L2 and nothing left to even out the CUs.  With one split's source data <= 2 MB, the splits a multiple of 8 and each split
+  // owned by one XCD (eval_kernel.hpp) the launch has 8-32 x more workgroups than the chip holds at once: 1.3-2.8 % faster (Stokeslet 2^18,
+  // SL+DL 2^20, Helmholtz 2^20).  Bounded: at most 64 splits, at most 4 GB of partial sums; problems under 2^34 pairs keep the old plan.
+#if !(defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_NO_L2_SPLITS))   // (the A/B build of tools/ab_eval_l2_splits.sh switches the rule off)
+  if ((double)Nt * (double)Ns >= 17179869184.0) {
+    const int64_t rs = (real == SCTL_AMD_F64 ? 8 : 4);
+    const int64_t src_bytes = Ns * (3 + k.nd + k.k0) * rs;
     int64_t s2 = (src_bytes + (2 << 20) - 1) / (2 << 20);
+    s2 = (s2 + 7) / 8 * 8;
+    if (s2 > 64) s2 = 64;
+    const int64_t ws_cap = ((int64_t)4 << 30) / (Nt * k.k1 * rs) / 8 * 8;
+    if (s2 > ws_cap) s2 = ws_cap;
     if (s2 > s) s = s2;
-    if (s >= 5) s = (s + 7) / 8 * 8;
     if (s > ntile) s = ntile;
   }
 #endif

@@ -1,13 +1,13 @@
 #!/bin/bash
-# ONE A/B: the exact all-pairs kernel with source splits of <= 2 MB in multiples of 8, each owned by one XCD
-# (tools/ab/libsctl_amd_l2splits.so: make -C sctl_amd/csrc EXTRA="-DSCTL_AMD_EXPERIMENTS -DSCTL_AMD_EXP_L2_SPLITS" OUT=... OBJDIR=...) against the
-# shipped plan (few, large splits; the XCD-aware mapping only where the splits already come in eights).  Per workload and library: step time from
+# A/B: the exact all-pairs kernel with source splits of <= 2 MB in multiples of 8, each owned by one XCD (the shipped
+# library) against the round-2 plan — few, large splits; the XCD-aware mapping only where the splits already come in eights —
+# (tools/ab/libsctl_amd_nol2splits.so: make -C sctl_amd/csrc EXTRA="-DSCTL_AMD_EXPERIMENTS -DSCTL_AMD_EXP_NO_L2_SPLITS" OUT=... OBJDIR=...).  Per workload and library: step time from
 # bench.py, and FETCH_SIZE / WRITE_SIZE of the dominant kernel from two rocprofv3 --pmc passes.
 out=$PWD/gpurun_out/ab_l2splits; mkdir -p $out
 root=$PWD
 for w in stokeslet laplace_sldl helmholtz; do
-  for lib in shipped l2splits; do
-    if [ $lib = l2splits ]; then export SCTL_AMD_LIB=$root/tools/ab/libsctl_amd_l2splits.so; else unset SCTL_AMD_LIB; fi
+  for lib in shipped nol2splits; do
+    if [ $lib = nol2splits ]; then export SCTL_AMD_LIB=$root/tools/ab/libsctl_amd_nol2splits.so; else unset SCTL_AMD_LIB; fi
     python3 bench.py --workload $w --steps 4 --warmup 1 --no-cpu-baseline 2>/dev/null | python3 -c "
 import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$w $lib: %.2f ms/step  kernel %.2f ms  frac %.4f  plan %s' % (d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['frac'], d['config']['launch']))"
     for c in FETCH_SIZE WRITE_SIZE; do
