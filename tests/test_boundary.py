@@ -79,10 +79,19 @@ def test_launch_planner():
                     assert p["workgroups"] >= min(1024, ((N + 255) // 256) * ((N + 255) // 256))
                 k1 = sctl_amd.kernel_info(name)["k1"]
                 assert p["workspace_bytes"] == (0 if p["src_splits"] == 1 else p["src_splits"] * N * k1 * (8 if real == 0 else 4))
-    big = sctl_amd.plan("Stokes3D-FxU", 0, 1 << 20, 1 << 20)
-    assert big["src_splits"] == 1 and big["workspace_bytes"] == 0 and big["trg_per_lane"] == 2 and big["path"] == "exact"
+    # the exact kernel from 2^34 pairs on: a split's source data <= 2 MB, splits in eights (one share per XCD), <= 64 splits, <= 4 GB of partial sums
+    for name, real, logn in (("Stokes3D-FxU", 0, 20), ("Stokes3D-FxU", 0, 18), ("Laplace3D-FDxUdU", 0, 20), ("Helmholtz3D-FxU", 0, 20), ("Stokes3D-FxT", 1, 23),
+                             ("Laplace3D-FxdU", 0, 17)):
+        p, i = sctl_amd.plan(name, real, 1 << logn, 1 << logn), sctl_amd.kernel_info(name)
+        rs = 8 if real == 0 else 4
+        assert p["path"] == "exact" and p["trg_per_lane"] == 2 and p["src_splits"] % 8 == 0 and 8 <= p["src_splits"] <= 64, (name, p)
+        assert p["workspace_bytes"] <= 4 << 30
+        assert ((rs * (3 + i["nd"] + i["k0"]) << logn) / p["src_splits"] <= (2 << 20) or p["src_splits"] == 64 or
+                (p["src_splits"] + 8) * (i["k1"] * rs << logn) > 4 << 30), (name, p)
+    assert sctl_amd.plan("Stokes3D-FxU", 0, 1 << 20, 1 << 20)["src_splits"] == 24
+    assert sctl_amd.plan("Stokes3D-FxU", 0, 1 << 16, 1 << 16)["src_splits"] == 16          # under 2^34 pairs the old rule: 8 workgroups per CU, no more
     small = sctl_amd.plan("Laplace3D-FxU", 0, 1 << 14, 1 << 14)
-    assert small["src_splits"] > 1 and small["path"] == "exact"
+    assert small["src_splits"] == 16 and small["path"] == "exact"
     if os.environ.get("SCTL_AMD_CENTERED") != "0":      # the headline problem takes the tile-centred Laplace path: one wave per workgroup
         head = sctl_amd.plan("Laplace3D-FxU", 0, 1 << 20, 1 << 20)
         assert head["path"] == "tile-centred" and head["src_splits"] == 16 and head["workgroups"] == 8192 * 16
