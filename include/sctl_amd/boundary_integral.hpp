@@ -178,11 +178,6 @@ template <class Real, class Kernel> class BoundaryIntegralOp {
     CheckStatus(rc, "sctl_amd_op_eval");
   }
 
-  // boundary_integral.txx:616-680: scale the dofs of every element by sqrt(element area) (or its inverse), the area being
-  // the sum of the element's far-field quadrature weights at tolerance 1 — used to symmetrise second-kind formulations.
-  void SqrtScaling(Vector<Real>& U) const { ScaleByElementArea(U, false); }
-  void InvSqrtScaling(Vector<Real>& U) const { ScaleByElementArea(U, true); }
-
   // boundary_integral.txx:608-614: far field, then the near-zone correction added to it.  Here both run in ONE pass over the devices of
   // the far-field operator (sctl_amd_op_eval_potential): the densities go down once, the near field is accumulated into the far-field
   // result where it lies (each device holds the columns of K_near that belong to its target slab), the potential comes up once.
@@ -576,28 +571,6 @@ template <class Real, class Kernel> class BoundaryIntegralOp {
     setup_near_flag = true;
   }
 
-  void ScaleByElementArea(Vector<Real>& U, bool inverse) const {
-    SetupBasic();
-    const Long Nelem = elem_nds_cnt.Dim();
-    const Long Nnodes = (Nelem ? elem_nds_dsp[Nelem - 1] + elem_nds_cnt[Nelem - 1] : 0);
-    const Long dof = (Nnodes ? U.Dim() / Nnodes : 0);
-    SCTL_AMD_ASSERT(U.Dim() == Nnodes * dof);
-    for (Long i = 0; i < (Long)elem_lst_name.size(); i++) {
-      Vector<Real> X, Xn, wts, dist;
-      Vector<Long> cnt;
-      elem_lst_map.at(elem_lst_name[i])->GetFarFieldNodes(X, Xn, wts, dist, cnt, (Real)1);
-      SCTL_AMD_ASSERT(cnt.Dim() == elem_lst_cnt[i]);
-      Long w0 = 0;
-      for (Long j = 0; j < elem_lst_cnt[i]; j++) {
-        Real area = 0;
-        for (Long q = 0; q < cnt[j]; q++) area += wts[w0 + q];
-        w0 += cnt[j];
-        const Real s = inverse ? 1 / std::sqrt(area) : std::sqrt(area);
-        const Long e = elem_lst_dsp[i] + j;
-        for (Long q = elem_nds_dsp[e] * dof; q < (elem_nds_dsp[e] + elem_nds_cnt[e]) * dof; q++) U[q] *= s;
-      }
-    }
-  }
   int fmm_digits() const { return (int)(std::log(tol_) / std::log(0.1)) + 1; }   // tolerance -> digits, as :520
   void ReleaseFarOp() const {
     if (far_op) sctl_amd_op_destroy(far_op);

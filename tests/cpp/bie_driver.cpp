@@ -245,18 +245,6 @@ template <class Kernel> int run(long seed, Long Nt, Long Ns, Long npe, Long ups,
   } else {
     for (Long i = 0; i < U.Dim(); i++) SCTL_AMD_ASSERT(U[i] == U2[i]);   // no near zone: ComputePotential == ComputeFarField
   }
-  {  // SqrtScaling / InvSqrtScaling (boundary_integral.txx:616-680): element e scales by sqrt(sum of its weights)
-    Vector<Real> g = f;
-    op.SqrtScaling(g);
-    for (Long e = 0; nfree == 0 && e * npe < Ns; e++) {   // (one list: element e = nodes [e npe, (e+1) npe))
-      Real area = 0;
-      for (Long j = e * npe; j < std::min<Long>((e + 1) * npe, Ns); j++) area += w[j];
-      for (Long j = e * npe * Kernel::SrcDim(); j < std::min<Long>((e + 1) * npe, Ns) * Kernel::SrcDim(); j++)
-        SCTL_AMD_ASSERT(std::fabs(g[j] - f[j] * std::sqrt(area)) <= 1e-14 * std::fabs(f[j]));
-    }
-    op.InvSqrtScaling(g);
-    for (Long j = 0; j < f.Dim(); j++) SCTL_AMD_ASSERT(std::fabs(g[j] - f[j]) <= 1e-14 * std::fabs(f[j]));
-  }
   U.Write(out);
   std::cout << "dim0=" << op.Dim(0) << " dim1=" << op.Dim(1) << '\n';
   return 0;
