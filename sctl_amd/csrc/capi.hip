@@ -188,6 +188,7 @@ Plan make_plan(const KernelEntry& k, int real, int64_t Nt, int64_t Ns) {
     const int64_t ws_cap = ((int64_t)4 << 30) / (Nt * k.k1 * rs) / 8 * 8;
     if (s2 > ws_cap) s2 = ws_cap;
     if (s2 > s) s = s2;
+    if (s >= 8) s = (s + 7) / 8 * 8;      // in eights also when the workgroup count, not the L2, asked for the splits (the XCD mapping needs it)
     if (s > ntile) s = ntile;
   }
 #endif

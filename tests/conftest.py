@@ -17,6 +17,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
 
 
+def pytest_terminal_summary(terminalreporter):
+    """Say WHY a test was skipped in the last lines of the run (the driver records only the tail of `pytest -q`): on a one-GPU box the
+    RCCL tests that need one GPU per rank are skipped, and the record should show that rather than a bare `1 skipped`."""
+    for rep in terminalreporter.stats.get("skipped", []):
+        why = rep.longrepr[2] if isinstance(rep.longrepr, tuple) and len(rep.longrepr) == 3 else str(rep.longrepr)
+        terminalreporter.write_line("SKIPPED %s -- %s" % (rep.nodeid, why))
+
+
 def ctx_for(name):
     return np.array(HELMHOLTZ_K) if name.startswith("Helmholtz") else None
 

@@ -148,3 +148,29 @@ def test_reference_side_binding_compiles_against_the_real_reference(oracle_mod):
         assert (a["k0"], a["k1"], a["nd"], a["flops"]) == (b["k0"], b["k1"], b["nd"], b["flops"]) and abs(a["scale"] - b["scale"]) < 1e-15
     out = subprocess.run(["ldd", os.path.join(ROOT, "oracle", "_ref", "libsctl_ref_dropin.so")], capture_output=True, text=True).stdout
     assert "libsctl_amd.so" in out
+
+
+def test_dropin_device_list_from_the_environment(oracle_mod):
+    """sctl_dropin.hpp reads its process-wide device list once: SCTL_AMD_DEVICES (a list or `all`), else the launcher's node-local rank, else every
+    visible GPU; SCTL_AMD_MIN_PAIRS_PER_DEVICE sets the work-per-GPU threshold.  (One subprocess per environment: the list is a static.)"""
+    if oracle_mod.dropin() is None:
+        pytest.skip("oracle/_ref/libsctl_ref_dropin.so was not built (no reference tree where build() ran)")
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import sctl_amd, oracle; sctl_amd.lib(); print(oracle.dropin().get_devices(), sctl_amd.device_count())" % ROOT)
+    drop = ("SCTL_AMD_DEVICES", "OMPI_COMM_WORLD_LOCAL_RANK", "MV2_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID", "SLURM_LOCALID", "LOCAL_RANK", "SCTL_AMD_MIN_PAIRS_PER_DEVICE")
+    base = {k: v for k, v in os.environ.items() if k not in drop}
+
+    def run(**extra):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(base, **extra), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        (devs, min_pairs), n_gpu = eval(r.stdout.strip().splitlines()[-1].replace(") ", "), ", 1))
+        return devs, min_pairs, n_gpu
+
+    devs, min_pairs, n_gpu = run()
+    assert devs == list(range(max(n_gpu, 1))) and min_pairs == 1 << 32
+    assert run(SCTL_AMD_DEVICES="0,2,3")[0] == [0, 2, 3]
+    assert run(SCTL_AMD_DEVICES="all")[0] == list(range(max(n_gpu, 1)))
+    assert run(SCTL_AMD_DEVICES="1", SCTL_AMD_MIN_PAIRS_PER_DEVICE="12345")[:2] == ([1], 12345)
+    assert run(SLURM_LOCALID="5")[0] == [5 % n_gpu if n_gpu else 0]                 # one rank per GPU under a launcher
+    assert run(LOCAL_RANK="3", SCTL_AMD_DEVICES="0,1")[0] == [0, 1]                 # the explicit list wins

@@ -85,6 +85,27 @@ def test_full_size_target_subset_against_the_reference(O, seed, name):
         assert rel_l2(us, gold) <= tol, (c["key"], "reference", rel_l2(us, gold))
 
 
+@pytest.mark.parametrize("name,Nt,Ns", [("Stokes3D-FxU", 150001, 131075), ("Helmholtz3D-FxU", 70001, 300007), ("Laplace3D-FDxUdU", 33000, 600011),
+                                        ("Laplace3D-FxdU", 262147, 65601)])
+def test_ragged_sizes_under_the_l2_split_rule(O, name, Nt, Ns):
+    """From 2^34 pairs on the planner cuts the sources into splits of <= 2 MB, in eights, each owned by one XCD (the kernel remaps its launch
+    index to (tile, split)): ragged target and source counts — a last tile and a last split that are partly empty — against the oracle on a
+    target subset that includes the first and the last targets, and accumulate semantics through the partial-sum reduction."""
+    import torch
+    info = sctl_amd.kernel_info(name)
+    p = sctl_amd.plan(name, 0, Nt, Ns)
+    assert p["path"] == "exact" and p["src_splits"] >= 8, p          # (a multiple of 8 wherever the tile count allows: the XCD-aware mapping; else the plain one)
+    xt, xs, xn, f = _cloud(41, Nt, Ns, info)
+    rng = np.random.default_rng(42)
+    v0 = rng.random(Nt * info["k1"]) - 0.5
+    d = [torch.from_numpy(a).cuda() for a in (xt, xs, xn, f)]
+    u = sctl_amd.eval_device(name, *d, ctx=ctx_for(name), v_trg=torch.from_numpy(v0).cuda()).cpu().numpy().reshape(Nt, info["k1"])
+    sel = np.unique(np.concatenate([np.arange(300), np.arange(Nt - 300, Nt), rng.choice(Nt, 400, replace=False)]))
+    ref = O.eval(name, xt.reshape(Nt, 3)[sel].ravel().copy(), xs, xn, f, ctx=ctx_for(name)).reshape(-1, info["k1"])
+    got = u[sel] - v0.reshape(Nt, info["k1"])[sel]
+    assert rel_l2(got, ref) <= 1e-12, rel_l2(got, ref)
+
+
 def test_linearity_and_translation_invariance_at_scale():
     import torch
     name = "Stokes3D-FxU"
