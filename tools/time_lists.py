@@ -10,7 +10,9 @@ from sctl_amd.lists import grid_neighbour_lists
 
 N = 1 << 21
 rng = np.random.default_rng(0)
-for grid in (16, 32, 64):
+GRIDS = [int(g) for g in os.environ.get("LISTS_GRIDS", "16,32,64").split(",")]
+KERNELS = os.environ.get("LISTS_KERNELS", "Laplace3D-FxU,Stokes3D-FxU,Stokes3D-DxU").split(",")
+for grid in GRIDS:
     x = rng.random((N, 3))
     box = (np.floor(x[:, 0] * grid) * grid + np.floor(x[:, 1] * grid)) * grid + np.floor(x[:, 2] * grid)
     order = np.argsort(box, kind="stable")
@@ -18,7 +20,7 @@ for grid in (16, 32, 64):
     counts = np.bincount(box.astype(np.int64), minlength=grid ** 3)
     lists = grid_neighbour_lists(grid, counts, counts)
     dx = torch.from_numpy(x).cuda()
-    for name in ("Laplace3D-FxU", "Stokes3D-FxU", "Stokes3D-DxU"):
+    for name in KERNELS:
         info = sctl_amd.kernel_info(name)
         plan = sctl_amd.ListsPlan(name, np.float64, *lists, N, N)
         dn = torch.from_numpy(rng.random(N * info["nd"]) - 0.5).cuda()
