@@ -286,7 +286,8 @@ int sctl_amd_eval_lists_host(int kernel, int real, int64_t nlists, const int64_t
 void sctl_amd_counters(int64_t* pair_interactions, int64_t* sctl_flops);
 void sctl_amd_reset_counters(void);
 /* Frees the device scratch memory the library keeps per (device, stream) between calls (partial sums, the sort buffers
- * of the tile-centred path: up to ~0.3 GB per stream at 2^20 points).  Waits for the devices.  Optional. */
+ * of the tile-centred path: up to ~1 GB per stream at 2^20 points) and the operators sctl_amd_eval_host_multi keeps between
+ * calls (streams, device copies of the last coordinates, pinned staging; at most 8).  Waits for the devices.  Optional. */
 void sctl_amd_trim(void);
 
 /* Debugging switches (a bit mask; returns the previous mask).  SCTL_AMD_DEBUG_POISON_SCRATCH: every evaluation first fills the

