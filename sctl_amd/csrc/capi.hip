@@ -731,23 +731,28 @@ int sctl_amd_kernel_matrix_host(int kernel, int real, int64_t Nt, int64_t Ns, co
   const size_t rs = (real == SCTL_AMD_F64) ? 8 : 4;
   DeviceScope dev_scope_2(device);
   HIP_TRY(dev_scope_2.err);
-  StreamGuard st;
-  HIP_TRY(hipStreamCreateWithFlags(&st.s, hipStreamNonBlocking));
-  DevBuf dxt, dxs, dxn, dm;
+  // Stream, device buffers and pinned staging of the calling thread's slot for this device (shared with the Eval entry: a thread makes one
+  // call at a time): the reference's SetupNear calls KernelMatrix once per element from every thread of an OpenMP loop
+  // (boundary_integral.txx:949-986), thousands of small blocks, and four hipMalloc / hipFree pairs plus a stream per call cost more than
+  // the blocks themselves.
+  HostSlot& hs = host_slot(device);
+  if (!hs.st.s) HIP_TRY(hipStreamCreateWithFlags(&hs.st.s, hipStreamNonBlocking));
+  hipStream_t st = hs.st.s;
+  struct Release { HostSlot& h; ~Release() { h.trim((size_t)64 << 20); } } release{hs};
   const size_t mbytes = (size_t)Ns * k->k0 * Nt * k->k1 * rs;
-  HIP_TRY(dxt.alloc((size_t)Nt * 3 * rs));
-  HIP_TRY(dxs.alloc((size_t)Ns * 3 * rs));
-  HIP_TRY(dxn.alloc((size_t)Ns * k->nd * rs));
-  HIP_TRY(dm.alloc(mbytes));
-  static thread_local PinnedBuf stage;
-  HIP_TRY(stage.reserve(pad256((size_t)Nt * 3 * rs) + pad256((size_t)Ns * 3 * rs) + pad256((size_t)Ns * k->nd * rs)));
-  HIP_TRY(upload(dxt.p, r_trg, (size_t)Nt * 3 * rs, stage, st.s));
-  HIP_TRY(upload(dxs.p, r_src, (size_t)Ns * 3 * rs, stage, st.s));
-  if (k->nd) HIP_TRY(upload(dxn.p, n_src, (size_t)Ns * k->nd * rs, stage, st.s));
-  rc = sctl_amd_kernel_matrix_device(kernel, real, Nt, Ns, dxt.p, dxs.p, dxn.p, dm.p, digits, ctx, ctx_bytes, st.s);
+  const size_t b_xt = (size_t)Nt * 3 * rs, b_xs = (size_t)Ns * 3 * rs, b_xn = (size_t)Ns * k->nd * rs;
+  HIP_TRY(hs.buf[0].reserve(b_xt));
+  HIP_TRY(hs.buf[1].reserve(b_xs));
+  HIP_TRY(hs.buf[2].reserve(b_xn));
+  HIP_TRY(hs.buf[3].reserve(mbytes));
+  HIP_TRY(hs.stage.reserve(pad256(b_xt) + pad256(b_xs) + pad256(b_xn)));
+  HIP_TRY(upload(hs.buf[0].p, r_trg, b_xt, hs.stage, st));
+  HIP_TRY(upload(hs.buf[1].p, r_src, b_xs, hs.stage, st));
+  if (k->nd) HIP_TRY(upload(hs.buf[2].p, n_src, b_xn, hs.stage, st));
+  rc = sctl_amd_kernel_matrix_device(kernel, real, Nt, Ns, hs.buf[0].p, hs.buf[1].p, k->nd ? hs.buf[2].p : nullptr, hs.buf[3].p, digits, ctx, ctx_bytes, st);
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(M, dm.p, mbytes, hipMemcpyDeviceToHost, st.s));
-  HIP_TRY(hipStreamSynchronize(st.s));
+  HIP_TRY(hipMemcpyAsync(M, hs.buf[3].p, mbytes, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
   return SCTL_AMD_OK;
 }
 
