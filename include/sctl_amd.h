@@ -65,6 +65,13 @@ enum sctl_amd_status {
 int sctl_amd_version(void);
 const char* sctl_amd_last_error(void);          /* message of the last failure on the calling thread ("" if none) */
 int sctl_amd_device_count(void);                /* number of HIP devices visible, 0 if none (never an error)       */
+/* Optional (everything initialises lazily).  init: touch every visible GPU now, so that the first evaluation does not pay the runtime's
+ * first-use cost; returns the number of GPUs (0 without any: not an error) or a negative status.  finalize: give back what the library
+ * keeps between calls (sctl_amd_trim + the calling thread's cached streams, device buffers and pinned staging); the library stays
+ * usable afterwards.  Neither exists in the reference, whose CPU path has no such state; a patched SCTL calls them from Comm::MPI_Init /
+ * MPI_Finalize (comm.txx:117-140) if at all. */
+int sctl_amd_init(void);
+void sctl_amd_finalize(void);
 
 /* Kernel id for a functor's Name() string (kernel_functions.hpp:16-19), or SCTL_AMD_ERR_UNKNOWN_KERNEL:
  * the "is this kernel supported on the device" query of the header wrapper. */

@@ -20,7 +20,7 @@ KERNEL_NAMES = ["Laplace3D-FxU", "Laplace3D-DxU", "Laplace3D-FxdU", "Stokes3D-Fx
                 "Stokes3D-FxUP", "Laplace3D-FDxUdU", "Helmholtz3D-FxU"]
 
 # every symbol include/sctl_amd.h declares (tests/test_boundary.py checks the header against this list and the .so)
-SYMBOLS = ["sctl_amd_version", "sctl_amd_last_error", "sctl_amd_device_count", "sctl_amd_kernel_id", "sctl_amd_kernel_name",
+SYMBOLS = ["sctl_amd_version", "sctl_amd_last_error", "sctl_amd_device_count", "sctl_amd_init", "sctl_amd_finalize", "sctl_amd_kernel_id", "sctl_amd_kernel_name",
            "sctl_amd_kernel_info", "sctl_amd_flops_per_pair", "sctl_amd_eval_device", "sctl_amd_eval_device_slab", "sctl_amd_eval_host", "sctl_amd_eval_host_multi",
            "sctl_amd_kernel_matrix_device", "sctl_amd_kernel_matrix_host", "sctl_amd_kernel_matrix_batch_host", "sctl_amd_counters", "sctl_amd_reset_counters", "sctl_amd_trim",
            "sctl_amd_eval_plan", "sctl_amd_eval_path", "sctl_amd_op_create", "sctl_amd_op_set_targets",
@@ -107,6 +107,7 @@ def lib():
     L.sctl_amd_op_set_near.argtypes = [vp, ci, ci, i64, vp, vp, vp, vp, vp, vp, vp]
     L.sctl_amd_op_eval_potential.argtypes = [vp, vp, vp, vp, ci, ci, vp, ci]
     L.sctl_amd_load_plugin.argtypes = [C.c_char_p]
+    L.sctl_amd_finalize.restype = None
     L.sctl_amd_lists_create.argtypes = [ci, ci, ci, i64, vp, vp, vp, vp, i64, i64, C.POINTER(vp)]
     L.sctl_amd_lists_eval_device.argtypes = [vp, vp, vp, vp, vp, vp, ci, vp, ci, vp]
     L.sctl_amd_lists_eval_host.argtypes = [vp, vp, vp, vp, vp, vp, ci, vp, ci]
@@ -126,6 +127,19 @@ def last_error():
 def _check(rc, what):
     if rc != 0:
         raise SctlAmdError("%s failed with status %d: %s" % (what, rc, last_error()))
+
+
+def init():
+    """Touch every visible GPU now (optional): returns their number."""
+    n = lib().sctl_amd_init()
+    if n < 0:
+        raise SctlAmdError("init failed with status %d: %s" % (n, last_error()))
+    return n
+
+
+def finalize():
+    """Give back everything the library keeps between calls (optional; it stays usable)."""
+    lib().sctl_amd_finalize()
 
 
 def device_count():

@@ -382,8 +382,13 @@ struct HostSlot {
   }
   ~HostSlot() { for (auto& b : buf) b.release(); }
 };
-HostSlot& host_slot(int device) {
+std::vector<std::unique_ptr<HostSlot>>& host_slots() {
   static thread_local std::vector<std::unique_ptr<HostSlot>> slots;
+  return slots;
+}
+void host_slots_release() { host_slots().clear(); }   // the calling thread's slots: streams, device buffers and pinned staging go with them
+HostSlot& host_slot(int device) {
+  auto& slots = host_slots();
   for (auto& s : slots) if (s->device == device) return *s;
   slots.emplace_back(new HostSlot);
   slots.back()->device = device;
@@ -512,6 +517,24 @@ extern "C" {
 int sctl_amd_version(void) { return SCTL_AMD_VERSION; }
 const char* sctl_amd_last_error(void) { return g_err.c_str(); }
 int sctl_amd_device_count(void) { return device_count_quiet(); }
+
+// init / finalise.  Everything in this library initialises lazily, so neither call is required: init() takes the HIP
+// runtime's and every device's first-touch cost (context, code-object load: tens to hundreds of ms) out of the first evaluation and
+// reports how many GPUs there are; finalize() gives back what the library keeps between calls — the scratch blocks, the operators of the
+// host-buffer entry, the calling thread's cached streams / buffers / staging — and leaves it usable (the next call initialises again).
+int sctl_amd_init(void) {
+  const int n = device_count_quiet();
+  if (n <= 0) return 0;
+  RestoreDevice restore;
+  for (int d = 0; d < n; d++) {
+    if (hipSetDevice(d) != hipSuccess || hipFree(nullptr) != hipSuccess) { (void)hipGetLastError(); return fail(SCTL_AMD_ERR_HIP, "cannot initialise device " + std::to_string(d)); }
+  }
+  return n;
+}
+void sctl_amd_finalize(void) {
+  sctl_amd_trim();
+  host_slots_release();
+}
 
 int sctl_amd_kernel_id(const char* name) { return registry_find(name); }
 int sctl_amd_num_kernels(void) { return registry_size(); }

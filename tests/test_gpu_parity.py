@@ -388,3 +388,18 @@ def test_host_entries_leave_the_callers_current_device_alone(O):
     assert torch.cuda.current_device() == before
     assert float(torch.ones(8, device="cuda").sum()) == 8.0
     assert rel_l2(u, u2) <= 1e-14
+
+
+def test_init_and_finalize_are_optional_and_repeatable(O):
+    """sctl_amd_init touches every GPU and reports their number; sctl_amd_finalize gives back the cached operators, scratch blocks and this
+    thread's streams / buffers / staging — and the library goes on working (everything initialises lazily)."""
+    import torch
+    assert sctl_amd.init() == torch.cuda.device_count() == sctl_amd.device_count()
+    rng = np.random.default_rng(12)
+    xt, xs, f = rng.random(3000 * 3), rng.random(5000 * 3), rng.random(5000 * 3) - 0.5
+    ref = O.eval("Stokes3D-FxU", xt, xs, None, f)
+    for devices in ([0], [0, 0, 0]):
+        for _ in range(2):
+            assert rel_l2(sctl_amd.eval_host("Stokes3D-FxU", xt, xs, None, f, devices=devices), ref) < 1e-12
+            sctl_amd.finalize()
+    assert sctl_amd.init() == torch.cuda.device_count()
