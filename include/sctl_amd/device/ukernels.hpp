@@ -42,9 +42,13 @@ struct KerCtx { double v[4]; };
 // tile with MASKED = true — the result is identical to the always-masked evaluation.
 // The one constant that is not a hardware inline constant (3/8) lives in a VGPR pair for the whole kernel
 // (RsqConst, made opaque to the optimiser so that it is not re-materialised with v_mov per use).
+// (The two constants of the four-instruction cubic step rsqrt_cubic83 below: c = 1 + m 2^-25 with m = round(2/3 2^25), and k = 4 (c - 1) - (c - 1)^2,
+// both exact doubles.)  They are wave-uniform and live in scalar registers: an fp64 VALU instruction takes one scalar operand for free, and the
+// tile-centred kernel has no vector registers to spare.
+constexpr double kCubicC = 0x1.aaaaaa8000000p+0, kCubicK = 0x1.1c71c6e38e38ep+1;
 template <class R> struct RsqConst {
-  R c38;
-  __device__ __forceinline__ RsqConst() : c38(R(0.375)) { asm volatile("" : "+v"(c38)); }
+  R c38, c53, k209;
+  __device__ __forceinline__ RsqConst() : c38(R(0.375)), c53(R(kCubicC)), k209(R(kCubicK)) { asm volatile("" : "+v"(c38), "+s"(c53), "+s"(k209)); }
 };
 
 template <int MODE, bool MASKED> __device__ __forceinline__ double rsqrt_masked(double r2, const RsqConst<double>& K) {
@@ -207,18 +211,55 @@ template <bool MASKED, class R> __device__ __forceinline__ R rsqrt_newton2(R r2,
   return y * fma_(-a, y, R(3));
 }
 
+// MODE 2 (full precision, the default) for the same kernels: the CUBIC step without its normalisation, in FOUR instructions.
+// With w = r2 y0^2 = 1 - e the Halley polynomial 1 + e/2 + 3/8 e^2 is 3/8 (w^2 - 10/3 w + 5) = 3/8 ((w - 5/3)^2 + 20/9): a monic
+// quadratic in w, i.e. ONE FMA for z = r2 (y0 y0) - 5/3 and one for z z + 20/9 — the small quantity e is never formed —
+//     y0 ((r2 y0^2 - 5/3)^2 + 20/9) = (8/3) / r (1 + 5/16 e^3 + ...),
+// against five instructions for y0 + y0 e (1/2 + 3/8 e); the factor (8/3)^p goes into the scale applied once per target, as for MODE 1.
+// The constants need not BE 5/3 and 20/9, only be consistent: with c - 1 = B/2 and k = A - (c - 1)^2 the polynomial is A + B e + e^2, and what
+// matters is B / A = 1/2 to ~2^-31 (its error is multiplied by e <= 2^-23) and 1/A = 3/8 to ~2^-8 (multiplied by e^2).  So c - 1 is 2/3 rounded
+// to 25 bits, A = 4 (c - 1) = 2.666666627 and k = A - (c - 1)^2 are then EXACT doubles, B / A is exactly 1/2, 1/A is 3/8 (1 + 1.5e-8), and
+// the scale carries no rounding of the factor for p = 1 (cubic83_factor(3), (5) are A^3, A^5 correctly rounded).
+// Accuracy (tools/ubench/rsq_refine_accuracy.hip, 1.3e8 arguments against long double, profiles/r03_rsq_refine_accuracy.txt): three roundings
+// sit on the main path (y0 y0, the polynomial, the product) where Halley's correction term has one, so the worst case is that of the reference's
+// own default approx_rsqrt (2.5 ulp) rather than Halley's 1.25 ulp, with a smaller rms than the reference's.
+// With the masked seed y0 = 0 the result is 0; an unmasked coincident pair gives z = 0 * inf = NaN, which the speculative pass detects.
+constexpr double cubic83_factor(int p) { return p == 1 ? 0x1.5555550000000p+1 : p == 3 ? 0x1.2f684af684bdep+4 : 0x1.0db20937d5dcdp+7; }
+template <bool MASKED> __device__ __forceinline__ double rsqrt_cubic83(double r2, const RsqConst<double>& K) {
+  const double y = rsqrt_masked<0, MASKED>(r2, K);
+  const double z = __builtin_fma(r2, y * y, -K.c53);
+  return y * __builtin_fma(z, z, K.k209);
+}
+// fp32 never runs MODE 2 (capi.hip: mode_for); kept consistent with the shared scale factor
+template <bool MASKED> __device__ __forceinline__ float rsqrt_cubic83(float r2, const RsqConst<float>& K) { return rsqrt_masked<1, MASKED>(r2, K) * (float)cubic83_factor(1); }
+// 1/r times the factor Ker::acc_factor(MODE) accounts for, for a kernel whose terms all carry the same power of 1/r
+#if defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_HALLEY)   // A/B build of tools/ab_cubic83.sh: MODE 2 keeps the five-instruction Halley step
+template <int MODE, bool MASKED, class R> __device__ __forceinline__ R rsqrt_scaled(R r2, const RsqConst<R>& K) {
+  if constexpr (MODE == 1) return rsqrt_newton2<MASKED>(r2, K);
+  else return rsqrt_masked<MODE, MASKED>(r2, K);
+}
+constexpr double rsqrt_scaled_factor(int mode, int p) { return mode == 1 ? newton2_factor(p) : 1; }
+#else
+template <int MODE, bool MASKED, class R> __device__ __forceinline__ R rsqrt_scaled(R r2, const RsqConst<R>& K) {
+  if constexpr (MODE == 1) return rsqrt_newton2<MASKED>(r2, K);
+  else if constexpr (MODE == 2) return rsqrt_cubic83<MASKED>(r2, K);
+  else return rsqrt_masked<0, MASKED>(r2, K);
+}
+constexpr double rsqrt_scaled_factor(int mode, int p) { return mode == 1 ? newton2_factor(p) : mode == 2 ? cubic83_factor(p) : 1; }
+#endif
+
 // ---- Laplace single layer: u = f / r          (kernel_functions.hpp:15-31) -------------------------------
 struct Laplace3D_FxU {
   static constexpr int ID = 0, K0 = 1, K1 = 1, ND = 0, NREC = 4, FLOPS = 6;
   static constexpr const char* NAME = "Laplace3D-FxU";
   template <class R> using Consts = DefaultConsts<R>;
   static constexpr double scale() { return 1 / (4 * kPi); }
-  static constexpr double acc_factor(int mode) { return mode == 1 ? newton2_factor(1) : 1; }   // MODE 1 accumulates f (2/r)
+  static constexpr double acc_factor(int mode) { return rsqrt_scaled_factor(mode, 1); }   // MODE 1 accumulates f (2/r), MODE 2 f (8/3)/r
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0];
   }
   template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const Consts<R>& K) {
-    const R rinv = (MODE == 1) ? rsqrt_newton2<MASKED>(len2(d), K.rsq) : rsqrt_masked<MODE, MASKED>(len2(d), K.rsq);   // MODE 1: 2/r
+    const R rinv = rsqrt_scaled<MODE, MASKED>(len2(d), K.rsq);   // MODE 1: 2/r, MODE 2: (8/3)/r
     acc[0] = fma_(rec[3], rinv, acc[0]);
   }
 };
@@ -229,12 +270,12 @@ struct Laplace3D_DxU {
   static constexpr const char* NAME = "Laplace3D-DxU";
   template <class R> using Consts = DefaultConsts<R>;
   static constexpr double scale() { return 1 / (4 * kPi); }
-  static constexpr double acc_factor(int mode) { return mode == 1 ? newton2_factor(3) : 1; }   // MODE 1 accumulates (r.n f) (2/r)^3
+  static constexpr double acc_factor(int mode) { return rsqrt_scaled_factor(mode, 3); }   // MODE 1 accumulates (r.n f) (2/r)^3, MODE 2 ((8/3)/r)^3
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R* n, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = n[0] * f[0]; rec[4] = n[1] * f[0]; rec[5] = n[2] * f[0];
   }
   template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const Consts<R>& K) {
-    const R rinv = (MODE == 1) ? rsqrt_newton2<MASKED>(len2(d), K.rsq) : rsqrt_masked<MODE, MASKED>(len2(d), K.rsq);   // MODE 1: 2/r
+    const R rinv = rsqrt_scaled<MODE, MASKED>(len2(d), K.rsq);   // MODE 1: 2/r, MODE 2: (8/3)/r
     const R rinv3 = rinv * rinv * rinv;
     acc[0] = fma_(dot3(d, rec + 3), rinv3, acc[0]);
   }
@@ -246,12 +287,12 @@ struct Laplace3D_FxdU {
   static constexpr const char* NAME = "Laplace3D-FxdU";
   template <class R> using Consts = DefaultConsts<R>;
   static constexpr double scale() { return -1 / (4 * kPi); }
-  static constexpr double acc_factor(int mode) { return mode == 1 ? newton2_factor(3) : 1; }   // MODE 1 accumulates f r (2/r)^3
+  static constexpr double acc_factor(int mode) { return rsqrt_scaled_factor(mode, 3); }   // MODE 1 accumulates f r (2/r)^3, MODE 2 ((8/3)/r)^3
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0];
   }
   template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const Consts<R>& K) {
-    const R rinv = (MODE == 1) ? rsqrt_newton2<MASKED>(len2(d), K.rsq) : rsqrt_masked<MODE, MASKED>(len2(d), K.rsq);   // MODE 1: 2/r
+    const R rinv = rsqrt_scaled<MODE, MASKED>(len2(d), K.rsq);   // MODE 1: 2/r, MODE 2: (8/3)/r
     const R t = rinv * rinv * rinv * rec[3];
     for (int j = 0; j < 3; j++) acc[j] = fma_(t, d[j], acc[j]);
   }
@@ -280,13 +321,13 @@ struct Stokes3D_DxU {
   static constexpr const char* NAME = "Stokes3D-DxU";
   template <class R> using Consts = DefaultConsts<R>;
   static constexpr double scale() { return 3 / (4 * kPi); }
-  static constexpr double acc_factor(int mode) { return mode == 1 ? newton2_factor(5) : 1; }   // MODE 1 accumulates (...) (2/r)^5
+  static constexpr double acc_factor(int mode) { return rsqrt_scaled_factor(mode, 5); }   // MODE 1 accumulates (...) (2/r)^5, MODE 2 ((8/3)/r)^5
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R* n, const R* f) {
     for (int k = 0; k < 3; k++) { rec[k] = x[k]; rec[3 + k] = n[k]; rec[6 + k] = f[k]; }
     rec[9] = 0;
   }
   template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const Consts<R>& K) {
-    const R rinv = (MODE == 1) ? rsqrt_newton2<MASKED>(len2(d), K.rsq) : rsqrt_masked<MODE, MASKED>(len2(d), K.rsq);   // MODE 1: 2/r
+    const R rinv = rsqrt_scaled<MODE, MASKED>(len2(d), K.rsq);   // MODE 1: 2/r, MODE 2: (8/3)/r
     const R rinv2 = rinv * rinv;
     const R t = dot3(d, rec + 3) * dot3(d, rec + 6) * (rinv2 * rinv2 * rinv);
     for (int j = 0; j < 3; j++) acc[j] = fma_(t, d[j], acc[j]);
@@ -299,12 +340,12 @@ struct Stokes3D_FxT {
   static constexpr const char* NAME = "Stokes3D-FxT";
   template <class R> using Consts = DefaultConsts<R>;
   static constexpr double scale() { return -3 / (4 * kPi); }
-  static constexpr double acc_factor(int mode) { return mode == 1 ? newton2_factor(5) : 1; }   // MODE 1 accumulates (...) (2/r)^5
+  static constexpr double acc_factor(int mode) { return rsqrt_scaled_factor(mode, 5); }   // MODE 1 accumulates (...) (2/r)^5, MODE 2 ((8/3)/r)^5
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0]; rec[4] = f[1]; rec[5] = f[2];
   }
   template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const Consts<R>& K) {
-    const R rinv = (MODE == 1) ? rsqrt_newton2<MASKED>(len2(d), K.rsq) : rsqrt_masked<MODE, MASKED>(len2(d), K.rsq);   // MODE 1: 2/r
+    const R rinv = rsqrt_scaled<MODE, MASKED>(len2(d), K.rsq);   // MODE 1: 2/r, MODE 2: (8/3)/r
     const R rinv2 = rinv * rinv;
     const R t = dot3(d, rec + 3) * (rinv2 * rinv2 * rinv);
     for (int j = 0; j < 3; j++) {       // u_jk = u_kj: the upper triangle only (6 FMAs instead of 9); finish() fills in the rest

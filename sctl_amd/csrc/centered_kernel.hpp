@@ -78,6 +78,10 @@ template <int MODE> __device__ __forceinline__ f32x2 rsqrt_pair(f32x2 r2) {
   if (MODE >= 1) {   // more than 7 digits asked of fp32: the unnormalised Newton step, 2/r (matches rsqrt_newton2; acc_factor carries the 2)
     const f32x2 a = r2 * y;
     y = y * (f32x2{3.0f, 3.0f} - a * y);
+    if (MODE == 2) {   // (never launched: fp32 stops at MODE 1, capi.hip mode_for) the factor Ker::acc_factor(2) expects
+      const float k = (float)(rsqrt_scaled_factor(2, 1) / 2);
+      y = y * f32x2{k, k};
+    }
   }
   return y;
 }
@@ -121,7 +125,7 @@ template <class R> struct CenteredFxU {      // u += f / r
   }
   template <int MODE> static __device__ __forceinline__ void far_pair(R& acc, const R (&m2x)[3], R tt, const R (&b)[4], const Extra& e, const RsqConst<R>& K) {
     const R r2 = fma_(m2x[0], b[0], fma_(m2x[1], b[1], fma_(m2x[2], b[2], tt + b[3])));
-    acc = fma_(e.f, (MODE == 1) ? rsqrt_newton2<false>(r2, K) : rsqrt_masked<MODE, false>(r2, K), acc);   // MODE 1: 2/r, as Ker::pair (acc_factor)
+    acc = fma_(e.f, rsqrt_scaled<MODE, false>(r2, K), acc);   // MODE 1: 2/r, MODE 2: (8/3)/r, as Ker::pair (acc_factor)
   }
   // all T targets of the lane against one far source
   template <int MODE, int T> static __device__ __forceinline__ void far_pairs(R (&acc)[T], const R (&m2x)[T][3], const R (&tt)[T], const R (&b)[4], const Extra& e,
@@ -158,7 +162,7 @@ template <class R> struct CenteredDxU {      // u += ((x_t - x_s).n f) / r^3, wi
   }
   template <int MODE> static __device__ __forceinline__ void far_pair(R& acc, const R (&m2x)[3], R tt, const R (&b)[4], const Extra& e, const RsqConst<R>& K) {
     const R r2 = fma_(m2x[0], b[0], fma_(m2x[1], b[1], fma_(m2x[2], b[2], tt + b[3])));
-    const R y = (MODE == 1) ? rsqrt_newton2<false>(r2, K) : rsqrt_masked<MODE, false>(r2, K);                // MODE 1: 2/r, as Ker::pair (acc_factor)
+    const R y = rsqrt_scaled<MODE, false>(r2, K);                // MODE 1: 2/r, MODE 2: (8/3)/r, as Ker::pair (acc_factor)
     const R dn = fma_(m2x[0], e.g[0], fma_(m2x[1], e.g[1], fma_(m2x[2], e.g[2], e.g[3])));
     acc = fma_(dn, y * y * y, acc);
   }
