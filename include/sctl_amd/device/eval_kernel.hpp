@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(kBlock) SCTL_AMD_EVAL_ATTR eval_kernel(const E
     if (!PREFETCH) fetch_source(it);
     if (tid < ns) {
       R rec[NRECP] = {};
-      Ker::template pack<R>(rec, px, pn, pf);
+      pack_record<Ker, R, MODE>(rec, px, pn, pf);
 #pragma unroll
       for (int v = 0; v < NV; v++) {
         V w;
@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(kBlock) SCTL_AMD_EVAL_ATTR eval_kernel(const E
 #pragma unroll
   for (int j = 0; j < T; j++) {
     const int64_t t = tbase + j * kBlock + tid;
-    finish_acc<Ker, R>(acc[j]);
+    finish_acc<Ker, R, MODE>(acc[j]);
     if (t < a.Nt) {
       if (gridDim.y == 1) {
 #pragma unroll
@@ -265,9 +265,9 @@ __global__ void __launch_bounds__(kBlock) matrix_kernel(int64_t Nt, int64_t Ns, 
     for (int k = 0; k < K0; k++) f[k] = (k == k0) ? R(1) : R(0);
 #pragma unroll
     for (int k = 0; k < K1; k++) acc[k] = 0;
-    Ker::template pack<R>(rec, x, n, f);
+    pack_record<Ker, R, MODE>(rec, x, n, f);
     Ker::template pair<R, MODE, true>(acc, d, rec, ctx, K);
-    finish_acc<Ker, R>(acc);
+    finish_acc<Ker, R, MODE>(acc);
     R* row = M + ((s * K0 + k0) * Nt + t) * K1;
 #pragma unroll
     for (int k = 0; k < K1; k++) row[k] = acc[k] * scale;
@@ -312,9 +312,9 @@ __global__ void __launch_bounds__(kBlock) matrix_batch_kernel(const MatTile* __r
       for (int k = 0; k < K0; k++) f[k] = (k == k0) ? R(1) : R(0);
 #pragma unroll
       for (int k = 0; k < K1; k++) acc[k] = 0;
-      Ker::template pack<R>(rec, x, n, f);
+      pack_record<Ker, R, MODE>(rec, x, n, f);
       Ker::template pair<R, MODE, true>(acc, d, rec, ctx, K);
-      finish_acc<Ker, R>(acc);
+      finish_acc<Ker, R, MODE>(acc);
       R* row = M + w.m_off + (((int64_t)s * K0 + k0) * w.nt + t) * K1;
 #pragma unroll
       for (int k = 0; k < K1; k++) row[k] = acc[k] * scale;

@@ -27,6 +27,11 @@
 // functor's ctx_ptr payload, copied at launch.
 // Optional: `template <class R> static __device__ void finish(R (&acc)[K1])` is applied once to a target's sums before they are written —
 // for a kernel whose pair() fills only part of a symmetric output (ukernels.hpp: Stokes3D_FxT).
+// Optional, for a kernel that wants the cheaper UNNORMALISED reciprocal square roots of ukernels.hpp (rsqrt_scaled<MODE, MASKED>: 2 / r in MODE 1,
+// (8/3) / r in MODE 2, one instruction fewer each): acc_factor(mode) states what multiple of the kernel value pair() then accumulates
+// (rsqrt_scaled_factor(mode, p) for terms in r^-p) and the library divides the scale by it; `template <class R, int MODE> pack_mode(rec, x, n, f)`
+// replaces pack() when the record depends on the mode (a density kept pre-multiplied by rsqrt_scaled_c2(MODE): Stokes3D_FxU), and
+// `template <class R, int MODE> finish_mode(acc)` replaces finish() (outputs that accumulate different powers: Laplace3D_FDxUdU).
 // A kernel with per-launch constants of its own supplies a Consts type instead of DefaultConsts: it is built once per workgroup from
 // (double* lds) or, when it has such a constructor, from (double* lds, const KerCtx& ctx) — e.g. to derive scalar-register constants
 // from a wavenumber (ukernels.hpp: HelmholtzConsts) — and handed to every pair() call.

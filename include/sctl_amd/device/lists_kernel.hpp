@@ -115,7 +115,7 @@ __device__ __forceinline__ void lists_item(const ListArgs<R>& a, const ListItem&
     __syncthreads();   // previous tile fully consumed
     if (lane < ns) {
       R rec[NRECP] = {};
-      Ker::template pack<R>(rec, sx, sn, sf);
+      pack_record<Ker, R, MODE>(rec, sx, sn, sf);
 #pragma unroll
       for (int v = 0; v < NV; v++) {
         V w;
@@ -200,7 +200,7 @@ __device__ __forceinline__ void lists_item(const ListArgs<R>& a, const ListItem&
 #pragma unroll
   for (int j = 0; j < T; j++) {
     const int tl = SPLIT ? (lane & (P - 1)) : (j * kListWave + lane);
-    finish_acc<Ker, R>(acc[j]);
+    finish_acc<Ker, R, MODE>(acc[j]);
     if (tl < it.nt && (!SPLIT || rep == 0)) {
       const int64_t t = it.t0 + tl;
 #pragma unroll

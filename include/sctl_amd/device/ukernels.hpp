@@ -162,15 +162,29 @@ template <> struct HelmholtzConsts<double> {         // fp64: table-driven e^{ik
 };
 
 // A kernel whose pair() leaves some entries of acc to be derived from others — a symmetric output: the traction kernel fills the upper
-// triangle only — supplies `template <class R> static void finish(R (&acc)[K1])`; the evaluators apply it once, when the sums leave
-// the registers (finish_acc).
-template <class Ker, class R, class = void> struct FinishOf {
+// triangle only — supplies `template <class R> static void finish(R (&acc)[K1])`, or `template <class R, int MODE> static void finish_mode(...)`
+// when what is left to do depends on the accuracy mode (the fused Laplace kernel: its potential and its gradient accumulate different powers
+// of the unnormalised 1/r); the evaluators apply it once, when the sums leave the registers (finish_acc).
+template <class Ker, class R, int MODE, class = void, class = void> struct FinishOf {
   static __device__ __forceinline__ void apply(R (&)[Ker::K1]) {}
 };
-template <class Ker, class R> struct FinishOf<Ker, R, std::void_t<decltype(&Ker::template finish<R>)>> {
+template <class Ker, class R, int MODE, class V> struct FinishOf<Ker, R, MODE, std::void_t<decltype(&Ker::template finish<R>)>, V> {
   static __device__ __forceinline__ void apply(R (&acc)[Ker::K1]) { Ker::template finish<R>(acc); }
 };
-template <class Ker, class R> __device__ __forceinline__ void finish_acc(R (&acc)[Ker::K1]) { FinishOf<Ker, R>::apply(acc); }
+template <class Ker, class R, int MODE> struct FinishOf<Ker, R, MODE, void, std::void_t<decltype(&Ker::template finish_mode<R, MODE>)>> {
+  static __device__ __forceinline__ void apply(R (&acc)[Ker::K1]) { Ker::template finish_mode<R, MODE>(acc); }
+};
+template <class Ker, class R, int MODE> __device__ __forceinline__ void finish_acc(R (&acc)[Ker::K1]) { FinishOf<Ker, R, MODE>::apply(acc); }
+
+// The LDS record of one source: Ker::pack<R>, or `template <class R, int MODE> static void pack_mode(rec, x, n, f)` when the record depends on
+// the accuracy mode (kernels that keep a density pre-multiplied by a power of the unnormalised 1/r's factor, below).
+template <class Ker, class R, int MODE, class = void> struct PackOf {
+  static __device__ __forceinline__ void apply(R* rec, const R* x, const R* n, const R* f) { Ker::template pack<R>(rec, x, n, f); }
+};
+template <class Ker, class R, int MODE> struct PackOf<Ker, R, MODE, std::void_t<decltype(&Ker::template pack_mode<R, MODE>)>> {
+  static __device__ __forceinline__ void apply(R* rec, const R* x, const R* n, const R* f) { Ker::template pack_mode<R, MODE>(rec, x, n, f); }
+};
+template <class Ker, class R, int MODE> __device__ __forceinline__ void pack_record(R* rec, const R* x, const R* n, const R* f) { PackOf<Ker, R, MODE>::apply(rec, x, n, f); }
 
 // Per-kernel constants of a launch: Consts(lds, capacity, ctx) when the type takes the scratch capacity (in doubles) and the context,
 // Consts(lds, ctx) when it takes the context, Consts(lds) otherwise.
@@ -247,6 +261,11 @@ template <int MODE, bool MASKED, class R> __device__ __forceinline__ R rsqrt_sca
 }
 constexpr double rsqrt_scaled_factor(int mode, int p) { return mode == 1 ? newton2_factor(p) : mode == 2 ? cubic83_factor(p) : 1; }
 #endif
+// Kernels whose terms carry SEVERAL powers of 1/r — Stokeslet-like u = (f + (r.f) r / r^2) / r — can use the unnormalised y = C / r as well when
+// the record keeps the density twice: f for the dot product, whose term then carries y^3 = C^3 / r^3, and C^2 f for the term in y alone.  One
+// fp64 instruction per pair less, paid with K0 more reals per source in LDS; the factor C^3 goes into the scale.  rsqrt_scaled_c2 is C^2: 4
+// (exact) for the Newton step, A^2 (A has 24 bits: exact) for the cubic step, 1 for the bare seed.
+constexpr double rsqrt_scaled_c2(int mode) { return rsqrt_scaled_factor(mode, 1) == 1 ? 1.0 : mode == 1 ? 4.0 : cubic83_factor(1) * cubic83_factor(1); }
 
 // ---- Laplace single layer: u = f / r          (kernel_functions.hpp:15-31) -------------------------------
 struct Laplace3D_FxU {
@@ -300,18 +319,21 @@ struct Laplace3D_FxdU {
 
 // ---- Stokeslet: u_j = f_j / r + (r.f) r_j / r^3, scale 1/(8 pi)   (kernel_functions.hpp:74-95) -----------
 struct Stokes3D_FxU {
-  static constexpr int ID = 3, K0 = 3, K1 = 3, ND = 0, NREC = 6, FLOPS = 23;
+  static constexpr int ID = 3, K0 = 3, K1 = 3, ND = 0, NREC = 10, FLOPS = 23;
   static constexpr const char* NAME = "Stokes3D-FxU";
   template <class R> using Consts = DefaultConsts<R>;
   static constexpr double scale() { return 1 / (8 * kPi); }
-  static constexpr double acc_factor(int /*mode*/) { return 1; }   // what pair() accumulates, relative to the kernel value
-  template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
-    rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0]; rec[4] = f[1]; rec[5] = f[2];
+  static constexpr double acc_factor(int mode) { return rsqrt_scaled_factor(mode, 3); }   // pair() accumulates C^3 x the kernel value, C / r the mode's 1/r
+  // record: x, f (for the dot product), C^2 f (the term in 1/r alone; rsqrt_scaled_c2)
+  template <class R, int MODE> static __device__ __forceinline__ void pack_mode(R* rec, const R* x, const R*, const R* f) {
+    const R c2 = R(rsqrt_scaled_c2(MODE));
+    rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0]; rec[4] = f[1]; rec[5] = f[2]; rec[6] = c2 * f[0]; rec[7] = c2 * f[1]; rec[8] = c2 * f[2]; rec[9] = 0;
   }
+  template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R* n, const R* f) { pack_mode<R, 0>(rec, x, n, f); }
   template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const Consts<R>& K) {
-    const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K.rsq);
-    const R t = dot3(d, rec + 3) * (rinv * rinv);                                              // (r.f) / r^2
-    for (int j = 0; j < 3; j++) acc[j] = fma_(rinv, fma_(t, d[j], rec[3 + j]), acc[j]);       // (f_j + r_j (r.f) / r^2) / r: 1/r^3 is never formed
+    const R y = rsqrt_scaled<MODE, MASKED>(len2(d), K.rsq);                                  // C / r
+    const R t = dot3(d, rec + 3) * (y * y);                                                  // C^2 (r.f) / r^2
+    for (int j = 0; j < 3; j++) acc[j] = fma_(y, fma_(t, d[j], rec[6 + j]), acc[j]);         // C^3 (f_j + r_j (r.f) / r^2) / r: 1/r^3 is never formed
   }
 };
 
@@ -358,36 +380,40 @@ struct Stokes3D_FxT {
 
 // ---- Stokeslet + source/sink: u_j = f_j / r + ((r.f) + f_3) r_j / r^3   (kernel_functions.hpp:148-172) ------
 struct Stokes3D_FSxU {
-  static constexpr int ID = 6, K0 = 4, K1 = 3, ND = 0, NREC = 8, FLOPS = 26;
+  static constexpr int ID = 6, K0 = 4, K1 = 3, ND = 0, NREC = 10, FLOPS = 26;
   static constexpr const char* NAME = "Stokes3D-FSxU";
   template <class R> using Consts = DefaultConsts<R>;
   static constexpr double scale() { return 1 / (8 * kPi); }
-  static constexpr double acc_factor(int /*mode*/) { return 1; }   // what pair() accumulates, relative to the kernel value
-  template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
-    rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0]; rec[4] = f[1]; rec[5] = f[2]; rec[6] = f[3]; rec[7] = 0;
+  static constexpr double acc_factor(int mode) { return rsqrt_scaled_factor(mode, 3); }   // as the Stokeslet: C^3 x the kernel value
+  template <class R, int MODE> static __device__ __forceinline__ void pack_mode(R* rec, const R* x, const R*, const R* f) {
+    const R c2 = R(rsqrt_scaled_c2(MODE));
+    rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0]; rec[4] = f[1]; rec[5] = f[2]; rec[6] = f[3]; rec[7] = c2 * f[0]; rec[8] = c2 * f[1]; rec[9] = c2 * f[2];
   }
+  template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R* n, const R* f) { pack_mode<R, 0>(rec, x, n, f); }
   template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const Consts<R>& K) {
-    const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K.rsq);
-    const R t = fma_(d[2], rec[5], fma_(d[1], rec[4], fma_(d[0], rec[3], rec[6]))) * (rinv * rinv);   // ((r.f) + f_3) / r^2
-    for (int j = 0; j < 3; j++) acc[j] = fma_(rinv, fma_(t, d[j], rec[3 + j]), acc[j]);
+    const R y = rsqrt_scaled<MODE, MASKED>(len2(d), K.rsq);                                                 // C / r
+    const R t = fma_(d[2], rec[5], fma_(d[1], rec[4], fma_(d[0], rec[3], rec[6]))) * (y * y);               // C^2 ((r.f) + f_3) / r^2
+    for (int j = 0; j < 3; j++) acc[j] = fma_(y, fma_(t, d[j], rec[7 + j]), acc[j]);
   }
 };
 
 // ---- velocity + pressure: Stokeslet and p = (r.f) / r^3   (kernel_functions.hpp:174-198) -------------------
 struct Stokes3D_FxUP {
-  static constexpr int ID = 7, K0 = 3, K1 = 4, ND = 0, NREC = 6, FLOPS = 26;
+  static constexpr int ID = 7, K0 = 3, K1 = 4, ND = 0, NREC = 10, FLOPS = 26;
   static constexpr const char* NAME = "Stokes3D-FxUP";
   template <class R> using Consts = DefaultConsts<R>;
   static constexpr double scale() { return 1 / (8 * kPi); }
-  static constexpr double acc_factor(int /*mode*/) { return 1; }   // what pair() accumulates, relative to the kernel value
-  template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
-    rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0]; rec[4] = f[1]; rec[5] = f[2];
+  static constexpr double acc_factor(int mode) { return rsqrt_scaled_factor(mode, 3); }   // velocity as the Stokeslet; the pressure (r.f) / r^3 carries C^3 by itself
+  template <class R, int MODE> static __device__ __forceinline__ void pack_mode(R* rec, const R* x, const R*, const R* f) {
+    const R c2 = R(rsqrt_scaled_c2(MODE));
+    rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0]; rec[4] = f[1]; rec[5] = f[2]; rec[6] = c2 * f[0]; rec[7] = c2 * f[1]; rec[8] = c2 * f[2]; rec[9] = 0;
   }
+  template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R* n, const R* f) { pack_mode<R, 0>(rec, x, n, f); }
   template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const Consts<R>& K) {
-    const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K.rsq);
-    const R t = dot3(d, rec + 3) * (rinv * rinv);
-    for (int j = 0; j < 3; j++) acc[j] = fma_(rinv, fma_(t, d[j], rec[3 + j]), acc[j]);
-    acc[3] = fma_(t, rinv, acc[3]);
+    const R y = rsqrt_scaled<MODE, MASKED>(len2(d), K.rsq);
+    const R t = dot3(d, rec + 3) * (y * y);
+    for (int j = 0; j < 3; j++) acc[j] = fma_(y, fma_(t, d[j], rec[6 + j]), acc[j]);
+    acc[3] = fma_(t, y, acc[3]);
   }
 };
 
@@ -399,24 +425,32 @@ template <class R> struct FDxUdUConsts : DefaultConsts<R> {   // + the constant 
   __device__ __forceinline__ explicit FDxUdUConsts(double* lds) : DefaultConsts<R>(lds), c3(R(3)) { asm volatile("" : "+v"(c3)); }
 };
 struct Laplace3D_FDxUdU {
-  static constexpr int ID = 8, K0 = 2, K1 = 4, ND = 3, NREC = 8, FLOPS = 28;
+  static constexpr int ID = 8, K0 = 2, K1 = 4, ND = 3, NREC = 10, FLOPS = 28;
   static constexpr const char* NAME = "Laplace3D-FDxUdU";
   template <class R> using Consts = FDxUdUConsts<R>;
   static constexpr double scale() { return 1 / (4 * kPi); }
-  static constexpr double acc_factor(int /*mode*/) { return 1; }   // what pair() accumulates, relative to the kernel value
-  template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R* n, const R* f) {
+  // With y = C / r (the mode's unnormalised 1/r) the gradient (m_j - r_j (q + 3 mu (r.n) / r^2)) / r^3 accumulates C^5 x its value when m and q are
+  // kept as C^2 m, C^2 q beside the plain m of the dot product; the potential (q + mu (r.n) / r^2) / r then carries C^3 and is multiplied by C^2
+  // once per target, when the sums leave the registers (finish_mode).
+  static constexpr double acc_factor(int mode) { return rsqrt_scaled_factor(mode, 5); }
+  // record: x, m = mu n (for the dot product), C^2 m, C^2 q
+  template <class R, int MODE> static __device__ __forceinline__ void pack_mode(R* rec, const R* x, const R* n, const R* f) {
+    const R c2 = R(rsqrt_scaled_c2(MODE));
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2];
-    rec[3] = n[0] * f[1]; rec[4] = n[1] * f[1]; rec[5] = n[2] * f[1]; rec[6] = f[0]; rec[7] = 0;
+    rec[3] = n[0] * f[1]; rec[4] = n[1] * f[1]; rec[5] = n[2] * f[1];
+    rec[6] = c2 * rec[3]; rec[7] = c2 * rec[4]; rec[8] = c2 * rec[5]; rec[9] = c2 * f[0];
   }
+  template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R* n, const R* f) { pack_mode<R, 0>(rec, x, n, f); }
   template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const Consts<R>& K) {
-    const R rinv = rsqrt_masked<MODE, MASKED>(len2(d), K.rsq);
-    const R rinv2 = rinv * rinv;
-    const R rinv3 = rinv2 * rinv;
-    const R w = dot3(d, rec + 3) * rinv2;               // mu (r.n) / r^2
-    acc[0] = fma_(w, rinv, fma_(rec[6], rinv, acc[0]));   // q / r + mu (r.n) / r^3
-    const R c = fma_(w, K.c3, rec[6]);                  // q + 3 mu (r.n) / r^2
-    for (int j = 0; j < 3; j++) acc[1 + j] = fma_(rinv3, fma_(-d[j], c, rec[3 + j]), acc[1 + j]);   // (m_j - r_j c) / r^3
+    const R y = rsqrt_scaled<MODE, MASKED>(len2(d), K.rsq);   // C / r
+    const R y2 = y * y;
+    const R y3 = y2 * y;
+    const R w = dot3(d, rec + 3) * y2;                      // C^2 mu (r.n) / r^2
+    acc[0] = fma_(w, y, fma_(rec[9], y, acc[0]));           // C^3 (q / r + mu (r.n) / r^3)
+    const R c = fma_(w, K.c3, rec[9]);                      // C^2 (q + 3 mu (r.n) / r^2)
+    for (int j = 0; j < 3; j++) acc[1 + j] = fma_(y3, fma_(-d[j], c, rec[6 + j]), acc[1 + j]);   // C^5 (m_j - r_j c) / r^3
   }
+  template <class R, int MODE> static __device__ __forceinline__ void finish_mode(R (&acc)[K1]) { acc[0] *= R(rsqrt_scaled_c2(MODE)); }
 };
 
 // ---- NEW: Helmholtz single layer G = exp(ikr)/r, complex k = ctx.v[0] + i ctx.v[1] (config 5)

@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(kWaveBlock) centered_kernel(const EvalArgs<R> 
   const R far_off = R(1.0e3) * (R(1) + sqrt_(rt2));
   auto put_near = [&](int q, const R (&xq)[3], const R (&nq)[3], const R (&fq)[1]) {
     R rec[4 * NEARW] = {};
-    Ker::template pack<R>(rec, xq, nq, fq);
+    pack_record<Ker, R, MODE>(rec, xq, nq, fq);
 #pragma unroll
     for (int g = 0; g < NEARW; g++) Rec4<R>::put(nearA + (q * NEARW + g) * NW, rec[4 * g], rec[4 * g + 1], rec[4 * g + 2], rec[4 * g + 3]);
   };
