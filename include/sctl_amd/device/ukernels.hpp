@@ -46,9 +46,13 @@ struct KerCtx { double v[4]; };
 // both exact doubles.)  They are wave-uniform and live in scalar registers: an fp64 VALU instruction takes one scalar operand for free, and the
 // tile-centred kernel has no vector registers to spare.
 constexpr double kCubicC = 0x1.aaaaaa8000000p+0, kCubicK = 0x1.1c71c6e38e38ep+1;
+// (and of its forms for r^-3 and r^-5, rsqrt3_cubic / rsqrt5_cubic: c = 7/5, k = 28/75 and c = 9/7, k = 36/245, rounded the same way)
+constexpr double kCubic3C = 0x1.6666660000000p+0, kCubic3K = 0x1.7e4b170a3d700p-2, kCubic5C = 0x1.4924920000000p+0, kCubic5K = 0x1.2cee3c14e5e00p-3;
 template <class R> struct RsqConst {
-  R c38, c53, k209;
-  __device__ __forceinline__ RsqConst() : c38(R(0.375)), c53(R(kCubicC)), k209(R(kCubicK)) { asm volatile("" : "+v"(c38), "+s"(c53), "+s"(k209)); }
+  R c38, c53, k209, c3, k3, c5, k5;
+  __device__ __forceinline__ RsqConst() : c38(R(0.375)), c53(R(kCubicC)), k209(R(kCubicK)), c3(R(kCubic3C)), k3(R(kCubic3K)), c5(R(kCubic5C)), k5(R(kCubic5K)) {
+    asm volatile("" : "+v"(c38), "+s"(c53), "+s"(k209), "+s"(c3), "+s"(k3), "+s"(c5), "+s"(k5));
+  }
 };
 
 template <int MODE, bool MASKED> __device__ __forceinline__ double rsqrt_masked(double r2, const RsqConst<double>& K) {
@@ -261,6 +265,45 @@ template <int MODE, bool MASKED, class R> __device__ __forceinline__ R rsqrt_sca
 }
 constexpr double rsqrt_scaled_factor(int mode, int p) { return mode == 1 ? newton2_factor(p) : mode == 2 ? cubic83_factor(p) : 1; }
 #endif
+// r^-3 and r^-5 for the kernels that need only that power (double layer, gradient, stresslet, traction).  MODE 2 does not cube the refined 1/r:
+// (1 - e)^(-3/2) = 1 + 3/2 e + 15/8 e^2 + ... and (1 - e)^(-5/2) = 1 + 5/2 e + 35/8 e^2 + ... are again monic quadratics in w = r2 y0^2 up to a
+// factor, 15/8 ((w - 7/5)^2 + 28/75) and 35/8 ((w - 9/7)^2 + 36/245), so
+//     y0 s ((r2 s - 7/5)^2 + 28/75) = (8/15) / r^3,      y0 s^2 ((r2 s - 9/7)^2 + 36/245) = (8/35) / r^5,      s = y0^2,
+// in five and six instructions where the cubic step and its powers take six and seven, and with fewer roundings on the way.  Constants as for
+// the first power: c - 1 = 2/5 (2/7) rounded to a 25-bit multiple of 3 (5), A = 4/3 (c - 1) (4/5 (c - 1)) and k = A - (c - 1)^2 exact doubles, so
+// that the ratio of the polynomial's first two coefficients is exactly 3/2 (5/2) and the factor A needs no rounding.
+constexpr double kCubic3A = 0x1.1111100000000p-1, kCubic5A = 0x1.d41d400000000p-3;
+template <bool MASKED> __device__ __forceinline__ double rsqrt3_cubic(double r2, const RsqConst<double>& K) {
+  const double y = rsqrt_masked<0, MASKED>(r2, K), s = y * y;
+  const double z = __builtin_fma(r2, s, -K.c3);
+  return (y * s) * __builtin_fma(z, z, K.k3);
+}
+template <bool MASKED> __device__ __forceinline__ double rsqrt5_cubic(double r2, const RsqConst<double>& K) {
+  const double y = rsqrt_masked<0, MASKED>(r2, K), s = y * y;
+  const double z = __builtin_fma(r2, s, -K.c5);
+  return (y * (s * s)) * __builtin_fma(z, z, K.k5);
+}
+#if defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_HALLEY)
+constexpr double rsqrt_pow_factor(int mode, int p) { return rsqrt_scaled_factor(mode, p); }
+#else
+constexpr double rsqrt_pow_factor(int mode, int p) { return mode == 2 ? (p == 1 ? cubic83_factor(1) : p == 3 ? kCubic3A : kCubic5A) : rsqrt_scaled_factor(mode, p); }
+#endif
+// r^-P times rsqrt_pow_factor(MODE, P), P = 3 or 5
+template <int MODE, int P, bool MASKED, class R> __device__ __forceinline__ R rsqrt_pow_scaled(R r2, const RsqConst<R>& K) {
+  static_assert(P == 3 || P == 5, "powers 3 and 5");
+#if !(defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_HALLEY))
+  if constexpr (MODE == 2 && std::is_same<R, double>::value) return P == 3 ? rsqrt3_cubic<MASKED>(r2, K) : rsqrt5_cubic<MASKED>(r2, K);
+  else if constexpr (MODE == 2) {   // fp32 never runs MODE 2 (capi.hip: mode_for); kept consistent with the shared scale factor
+    const R y = rsqrt_masked<1, MASKED>(r2, K), y2 = y * y;
+    return (P == 3 ? y2 * y : y2 * y2 * y) * R(rsqrt_pow_factor(2, P));
+  } else
+#endif
+  {
+    const R y = rsqrt_scaled<MODE, MASKED>(r2, K), y2 = y * y;
+    return P == 3 ? y2 * y : y2 * y2 * y;
+  }
+}
+
 // Kernels whose terms carry SEVERAL powers of 1/r — Stokeslet-like u = (f + (r.f) r / r^2) / r — can use the unnormalised y = C / r as well when
 // the record keeps the density twice: f for the dot product, whose term then carries y^3 = C^3 / r^3, and C^2 f for the term in y alone.  One
 // fp64 instruction per pair less, paid with K0 more reals per source in LDS; the factor C^3 goes into the scale.  rsqrt_scaled_c2 is C^2: 4
@@ -289,14 +332,12 @@ struct Laplace3D_DxU {
   static constexpr const char* NAME = "Laplace3D-DxU";
   template <class R> using Consts = DefaultConsts<R>;
   static constexpr double scale() { return 1 / (4 * kPi); }
-  static constexpr double acc_factor(int mode) { return rsqrt_scaled_factor(mode, 3); }   // MODE 1 accumulates (r.n f) (2/r)^3, MODE 2 ((8/3)/r)^3
+  static constexpr double acc_factor(int mode) { return rsqrt_pow_factor(mode, 3); }   // MODE 1 accumulates (r.n f) (2/r)^3, MODE 2 (r.n f) (8/15) / r^3
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R* n, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = n[0] * f[0]; rec[4] = n[1] * f[0]; rec[5] = n[2] * f[0];
   }
   template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const Consts<R>& K) {
-    const R rinv = rsqrt_scaled<MODE, MASKED>(len2(d), K.rsq);   // MODE 1: 2/r, MODE 2: (8/3)/r
-    const R rinv3 = rinv * rinv * rinv;
-    acc[0] = fma_(dot3(d, rec + 3), rinv3, acc[0]);
+    acc[0] = fma_(dot3(d, rec + 3), rsqrt_pow_scaled<MODE, 3, MASKED>(len2(d), K.rsq), acc[0]);
   }
 };
 
@@ -306,13 +347,12 @@ struct Laplace3D_FxdU {
   static constexpr const char* NAME = "Laplace3D-FxdU";
   template <class R> using Consts = DefaultConsts<R>;
   static constexpr double scale() { return -1 / (4 * kPi); }
-  static constexpr double acc_factor(int mode) { return rsqrt_scaled_factor(mode, 3); }   // MODE 1 accumulates f r (2/r)^3, MODE 2 ((8/3)/r)^3
+  static constexpr double acc_factor(int mode) { return rsqrt_pow_factor(mode, 3); }   // MODE 1 accumulates f r (2/r)^3, MODE 2 f r (8/15) / r^3
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0];
   }
   template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const Consts<R>& K) {
-    const R rinv = rsqrt_scaled<MODE, MASKED>(len2(d), K.rsq);   // MODE 1: 2/r, MODE 2: (8/3)/r
-    const R t = rinv * rinv * rinv * rec[3];
+    const R t = rsqrt_pow_scaled<MODE, 3, MASKED>(len2(d), K.rsq) * rec[3];
     for (int j = 0; j < 3; j++) acc[j] = fma_(t, d[j], acc[j]);
   }
 };
@@ -343,15 +383,13 @@ struct Stokes3D_DxU {
   static constexpr const char* NAME = "Stokes3D-DxU";
   template <class R> using Consts = DefaultConsts<R>;
   static constexpr double scale() { return 3 / (4 * kPi); }
-  static constexpr double acc_factor(int mode) { return rsqrt_scaled_factor(mode, 5); }   // MODE 1 accumulates (...) (2/r)^5, MODE 2 ((8/3)/r)^5
+  static constexpr double acc_factor(int mode) { return rsqrt_pow_factor(mode, 5); }   // MODE 1 accumulates (...) (2/r)^5, MODE 2 (...) (8/35) / r^5
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R* n, const R* f) {
     for (int k = 0; k < 3; k++) { rec[k] = x[k]; rec[3 + k] = n[k]; rec[6 + k] = f[k]; }
     rec[9] = 0;
   }
   template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const Consts<R>& K) {
-    const R rinv = rsqrt_scaled<MODE, MASKED>(len2(d), K.rsq);   // MODE 1: 2/r, MODE 2: (8/3)/r
-    const R rinv2 = rinv * rinv;
-    const R t = dot3(d, rec + 3) * dot3(d, rec + 6) * (rinv2 * rinv2 * rinv);
+    const R t = dot3(d, rec + 3) * dot3(d, rec + 6) * rsqrt_pow_scaled<MODE, 5, MASKED>(len2(d), K.rsq);
     for (int j = 0; j < 3; j++) acc[j] = fma_(t, d[j], acc[j]);
   }
 };
@@ -362,14 +400,12 @@ struct Stokes3D_FxT {
   static constexpr const char* NAME = "Stokes3D-FxT";
   template <class R> using Consts = DefaultConsts<R>;
   static constexpr double scale() { return -3 / (4 * kPi); }
-  static constexpr double acc_factor(int mode) { return rsqrt_scaled_factor(mode, 5); }   // MODE 1 accumulates (...) (2/r)^5, MODE 2 ((8/3)/r)^5
+  static constexpr double acc_factor(int mode) { return rsqrt_pow_factor(mode, 5); }   // MODE 1 accumulates (...) (2/r)^5, MODE 2 (...) (8/35) / r^5
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0]; rec[4] = f[1]; rec[5] = f[2];
   }
   template <class R, int MODE, bool MASKED> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx&, const Consts<R>& K) {
-    const R rinv = rsqrt_scaled<MODE, MASKED>(len2(d), K.rsq);   // MODE 1: 2/r, MODE 2: (8/3)/r
-    const R rinv2 = rinv * rinv;
-    const R t = dot3(d, rec + 3) * (rinv2 * rinv2 * rinv);
+    const R t = dot3(d, rec + 3) * rsqrt_pow_scaled<MODE, 5, MASKED>(len2(d), K.rsq);
     for (int j = 0; j < 3; j++) {       // u_jk = u_kj: the upper triangle only (6 FMAs instead of 9); finish() fills in the rest
       const R tj = t * d[j];
       for (int k = j; k < 3; k++) acc[j * 3 + k] = fma_(tj, d[k], acc[j * 3 + k]);

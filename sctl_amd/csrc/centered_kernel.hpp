@@ -73,13 +73,13 @@ constexpr int kNearCap = 128;    // capacity of the per-wave list of pending nea
 // instruction per SIMD at 4 waves), and the compiler only packs the final accumulate by itself.  The target-side quantities live as
 // {target 0, target 1} register pairs for the whole kernel; a source value is broadcast to both halves by the instruction's op_sel.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-template <int MODE> __device__ __forceinline__ f32x2 rsqrt_pair(f32x2 r2) {
+template <int MODE, int P = 1> __device__ __forceinline__ f32x2 rsqrt_pair(f32x2 r2) {   // the P-th power of the result is what the caller accumulates
   f32x2 y = {__builtin_amdgcn_rsqf(r2[0]), __builtin_amdgcn_rsqf(r2[1])};
   if (MODE >= 1) {   // more than 7 digits asked of fp32: the unnormalised Newton step, 2/r (matches rsqrt_newton2; acc_factor carries the 2)
     const f32x2 a = r2 * y;
     y = y * (f32x2{3.0f, 3.0f} - a * y);
-    if (MODE == 2) {   // (never launched: fp32 stops at MODE 1, capi.hip mode_for) the factor Ker::acc_factor(2) expects
-      const float k = (float)(rsqrt_scaled_factor(2, 1) / 2);
+    if (MODE == 2) {   // (never launched: fp32 stops at MODE 1, capi.hip mode_for) the factor Ker::acc_factor(2) expects of the P-th power
+      const float k = (float)__builtin_pow(rsqrt_pow_factor(2, P), 1.0 / P) / 2;
       y = y * f32x2{k, k};
     }
   }
@@ -162,9 +162,9 @@ template <class R> struct CenteredDxU {      // u += ((x_t - x_s).n f) / r^3, wi
   }
   template <int MODE> static __device__ __forceinline__ void far_pair(R& acc, const R (&m2x)[3], R tt, const R (&b)[4], const Extra& e, const RsqConst<R>& K) {
     const R r2 = fma_(m2x[0], b[0], fma_(m2x[1], b[1], fma_(m2x[2], b[2], tt + b[3])));
-    const R y = rsqrt_scaled<MODE, false>(r2, K);                // MODE 1: 2/r, MODE 2: (8/3)/r, as Ker::pair (acc_factor)
+    const R y3 = rsqrt_pow_scaled<MODE, 3, false>(r2, K);        // MODE 1: (2/r)^3, MODE 2: (8/15)/r^3, as Ker::pair (acc_factor)
     const R dn = fma_(m2x[0], e.g[0], fma_(m2x[1], e.g[1], fma_(m2x[2], e.g[2], e.g[3])));
-    acc = fma_(dn, y * y * y, acc);
+    acc = fma_(dn, y3, acc);
   }
   template <int MODE, int T> static __device__ __forceinline__ void far_pairs(R (&acc)[T], const R (&m2x)[T][3], const R (&tt)[T], const R (&b)[4], const Extra& e,
                                                                                 const RsqConst<R>& K) {
@@ -174,7 +174,7 @@ template <class R> struct CenteredDxU {      // u += ((x_t - x_s).n f) / r^3, wi
       r2 = mz * f32x2{b[2], b[2]} + r2;
       r2 = my * f32x2{b[1], b[1]} + r2;
       r2 = mx * f32x2{b[0], b[0]} + r2;
-      const f32x2 y = rsqrt_pair<MODE>(r2);
+      const f32x2 y = rsqrt_pair<MODE, 3>(r2);
       f32x2 dn = pk_fma_lo_hi(mz, f32x2{e.g[2], e.g[3]});
       dn = my * f32x2{e.g[1], e.g[1]} + dn;
       dn = mx * f32x2{e.g[0], e.g[0]} + dn;
