@@ -189,8 +189,13 @@ template <class R> struct CenteredDxU {      // u += ((x_t - x_s).n f) / r^3, wi
 
 // a.xt: Morton-sorted targets; a.v_trg / a.partial: indexed like a.xt (the caller scatters back).
 // (asking the compiler for 5-6 waves/SIMD instead of the 4 its 118 VGPRs allow costs 1-3 %: measured 464-471 vs 458 ms)
+#if defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_CENTERED_WAVES)   // A/B builds of tools/ab_centered_occupancy.sh: waves per SIMD asked of the compiler
+#define SCTL_AMD_CENTERED_ATTR __attribute__((amdgpu_waves_per_eu(SCTL_AMD_EXP_CENTERED_WAVES, SCTL_AMD_EXP_CENTERED_WAVES)))
+#else
+#define SCTL_AMD_CENTERED_ATTR
+#endif
 template <class CP, class R, int MODE, int T, int UNR = 4>
-__global__ void __launch_bounds__(kWaveBlock) centered_kernel(const EvalArgs<R> a) {
+__global__ void __launch_bounds__(kWaveBlock) SCTL_AMD_CENTERED_ATTR centered_kernel(const EvalArgs<R> a) {
   using V = typename Rec4<R>::V;
   constexpr int NW = Rec4<R>::NW;
   using Ker = typename CP::Ker;
