@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(kBlock) SCTL_AMD_EVAL_ATTR eval_kernel(const E
   using KC = typename Ker::template Consts<R>;
   constexpr int SCRATCH = AllPairsScratch<KC>::value;   // this evaluator's workgroups are long-lived: a kernel may ask for larger tables here
   __shared__ double kscratch[SCRATCH > 0 ? SCRATCH : 1];
-  const KC K = make_consts<KC>(kscratch, SCRATCH, a.ctx);
+  const KC K = make_consts<KC>(kscratch, SCRATCH, a.ctx, MODE);
 
   R xt[T][3], acc[T][K1];
 #pragma unroll
@@ -250,7 +250,7 @@ __global__ void __launch_bounds__(kBlock) matrix_kernel(int64_t Nt, int64_t Ns, 
   const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   using KC = typename Ker::template Consts<R>;
   __shared__ double kscratch[KC::LDS_DOUBLES > 0 ? KC::LDS_DOUBLES : 1];
-  const KC K = make_consts<KC>(kscratch, ctx);        // before the early return: the constructor may synchronise the workgroup
+  const KC K = make_consts<KC>(kscratch, ctx, MODE);        // before the early return: the constructor may synchronise the workgroup
   if (t >= Nt) return;
   for (int64_t s = blockIdx.y; s < Ns; s += gridDim.y) {   // gridDim.y is capped at 65535
   R x[3], n[3] = {0, 0, 0}, d[3];
@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(kBlock) matrix_batch_kernel(const MatTile* __r
   constexpr int K0 = Ker::K0, K1 = Ker::K1, ND = Ker::ND, NREC = Ker::NREC;
   using KC = typename Ker::template Consts<R>;
   __shared__ double kscratch[KC::LDS_DOUBLES > 0 ? KC::LDS_DOUBLES : 1];
-  const KC K = make_consts<KC>(kscratch, ctx);
+  const KC K = make_consts<KC>(kscratch, ctx, MODE);
   const MatTile w = tiles[blockIdx.x];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int t = w.t0 + lane;

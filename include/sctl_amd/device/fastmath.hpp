@@ -217,14 +217,24 @@ struct TabCoeffsK {
     q1 = hi / d;   // (an explicit FMA below: contraction cannot change it)
     q2 = (fma_(-q1, d, hi) + lo) / d;
   }
-  SCTL_AMD_HD void set(double kr, double kappa, const TabCoeffs& B) {
+  SCTL_AMD_HD void set(double kr, double kappa, const TabCoeffs& B) { set_scaled(kr, kappa, B, 1.0); }
+  // the same for a distance handed in as C r (see CexpCoeffsK::set_scaled): the constants of k / C, the two steps C h kept in two exact pieces
+  static SCTL_AMD_HD void mul2(double C, double hi, double lo, double& ph, double& pl) {
+    ph = C * hi;
+    pl = fma_(C, hi, -ph) + C * lo;
+  }
+  SCTL_AMD_HD void set_scaled(double kr_true, double kappa_true, const TabCoeffs& B, double C) {
+    const double kr = kr_true / C, kappa = kappa_true / C;
+    double ph, pl;
     ih = B.inv_h * kr;
-    if (kr != 0) div2(B.h1, B.h2, kr, h1, h2); else h1 = h2 = 0;
+    mul2(C, B.h1, B.h2, ph, pl);
+    if (kr != 0) div2(ph, pl, kr_true, h1, h2); else h1 = h2 = 0;
     const double k2 = kr * kr;
     s0 = kr; s1 = B.s1 * k2 * kr; s2 = B.s2 * k2 * k2 * kr;
     c1 = B.c1 * k2; c2 = B.c2 * k2 * k2;
     ie = B.inv_e * kappa;
-    if (kappa != 0) div2(B.e1, B.e2, kappa, e1, e2); else e1 = e2 = 0;
+    mul2(C, B.e1, B.e2, ph, pl);
+    if (kappa != 0) div2(ph, pl, kappa_true, e1, e2); else e1 = e2 = 0;
     const double a2 = kappa * kappa;
     p1 = kappa; p2 = 0.5 * a2; p3 = B.p2 * a2 * kappa; p4 = B.p3 * a2 * a2;
   }
@@ -291,9 +301,16 @@ struct CexpCoeffsK {
   double ih, h1, h2;                               // 1/h and -h in two pieces
   double a1r, a1i, a2r, a2i, a3r, a3i, a4r, a4i;   // (kappa + i kr)^m / m!
   static SCTL_AMD_HD bool usable(double kr, double kappa) { return kr > 0 && __builtin_fabs(kappa) <= kCexpMaxDecayRatio * kr && kr < 1e150 && kr > 1e-150; }
-  SCTL_AMD_HD void set(double kr, double kappa, const TabCoeffs& B) {
-    ih = (4 * B.inv_h) * kr;                       // 2048 / (2 pi) x kr
-    TabCoeffsK::div2(B.h1 / 4, B.h2 / 4, kr, h1, h2);   // -(pi/1024) / kr
+  SCTL_AMD_HD void set(double kr, double kappa, const TabCoeffs& B) { set_scaled(kr, kappa, B, 1.0); }
+  // For a distance handed in as C r (the kernels' unnormalised reciprocal square root gives C / r, and r2 (C / r) = C r costs no more than r):
+  // the constants of the wavenumber k / C.  The step C h keeps its two-piece accuracy — C (24 significant bits or a power of two) times the
+  // 33-bit head is split exactly by one FMA —; the reciprocal step and the polynomial coefficients only need rounding accuracy.
+  SCTL_AMD_HD void set_scaled(double kr_true, double kappa_true, const TabCoeffs& B, double C) {
+    const double kr = kr_true / C, kappa = kappa_true / C;
+    ih = (4 * B.inv_h) * kr;                       // 2048 / (2 pi) x kr / C
+    double ph, pl;
+    TabCoeffsK::mul2(C, B.h1 / 4, B.h2 / 4, ph, pl);
+    TabCoeffsK::div2(ph, pl, kr_true, h1, h2);     // -(pi/1024) C / kr
     // powers of c = kappa + i kr
     const double c2r = kappa * kappa - kr * kr, c2i = 2 * kappa * kr;
     const double c3r = c2r * kappa - c2i * kr, c3i = c2r * kr + c2i * kappa;

@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(kListWave) lists_kernel(const ListArgs<R> a) {
   __shared__ V tile[kListTile * NV];
   using KC = typename Ker::template Consts<R>;
   __shared__ double kscratch[KC::LDS_DOUBLES > 0 ? KC::LDS_DOUBLES : 1];
-  const KC K = make_consts<KC>(kscratch, a.ctx);
+  const KC K = make_consts<KC>(kscratch, a.ctx, MODE);
   // Workgroups are dealt round-robin over the 8 XCDs (blocks b, b + 8, ... share one, each XCD with its own L2): XCD x walks ITS
   // share of the item list — a spatially contiguous run of target boxes holding 1/8 of the pair count (lists.hip) — so that the
   // items of one box (consecutive in the list, all streaming the same source boxes) and of its neighbours meet in ONE L2 instead

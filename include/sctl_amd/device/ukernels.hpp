@@ -100,6 +100,13 @@ template <class R> struct DefaultConsts {
   __device__ __forceinline__ void begin_tile() const {}
   __device__ __forceinline__ bool tile_bad(const KerCtx&) const { return false; }
 };
+// The Helmholtz kernel runs on the modes' unnormalised reciprocal square roots too (rsqrt_scaled below: C / r with C = 2 for MODE 1, A = 2.6666666 for
+// MODE 2): the amplitude's C goes into the scale, and the distance comes out as r2 (C / r) = C r at the price of the normalised one.  C by mode:
+#if defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_HALLEY)
+constexpr double helmholtz_dist_factor(int mode) { return mode == 1 ? 2.0 : 1.0; }
+#else
+constexpr double helmholtz_dist_factor(int mode) { return mode == 1 ? 2.0 : mode == 2 ? 0x1.5555550000000p+1 : 1.0; }
+#endif
 template <class R> struct HelmholtzConsts;
 template <> struct HelmholtzConsts<float> {          // fp32: libm sincosf / expf
   static constexpr int LDS_DOUBLES = 0;
@@ -107,7 +114,9 @@ template <> struct HelmholtzConsts<float> {          // fp32: libm sincosf / exp
   static constexpr int NUM_VARIANTS = 2;
   __device__ __forceinline__ int variant(const KerCtx& ctx) const { return ctx.v[1] == 0 ? 1 : 0; }
   RsqConst<float> rsq;
+  float cinv = 1.0f;       // 1 / C: pair() forms C r from the mode's unnormalised C / r (helmholtz_dist_factor)
   __device__ __forceinline__ explicit HelmholtzConsts(double*) {}
+  __device__ __forceinline__ HelmholtzConsts(double*, int, const KerCtx&, int mode) : cinv((float)(1.0 / helmholtz_dist_factor(mode))) {}
   __device__ __forceinline__ void begin_tile() const {}
   __device__ __forceinline__ bool tile_bad(const KerCtx&) const { return false; }
 };
@@ -126,8 +135,10 @@ template <> struct HelmholtzConsts<double> {         // fp64: table-driven e^{ik
   fastmath::TabCoeffsK tk;     // reduction and polynomial constants with the launch's wavenumber folded in: functions of the distance
   fastmath::CexpCoeffsK ck;    // the same for the one-reduction form
   const double* table;
-  // (a Consts type constructible from (double*, int, const KerCtx&) is handed the scratch capacity and the launch's context: make_consts below)
-  __device__ __forceinline__ HelmholtzConsts(double* lds, int lds_doubles, const KerCtx& ctx) : table(lds) {
+  double cdist, cinv;          // C and 1 / C of the distance pair() hands over (C r)
+  // (a Consts type constructible from (double*, int, const KerCtx&[, int mode]) is handed the scratch capacity, the launch's context and its accuracy mode: make_consts below)
+  __device__ __forceinline__ HelmholtzConsts(double* lds, int lds_doubles, const KerCtx& ctx) : HelmholtzConsts(lds, lds_doubles, ctx, 0) {}
+  __device__ __forceinline__ HelmholtzConsts(double* lds, int lds_doubles, const KerCtx& ctx, int mode) : table(lds), cdist(helmholtz_dist_factor(mode)), cinv(1.0 / helmholtz_dist_factor(mode)) {
 #ifdef SCTL_AMD_EXP_HELMHOLTZ_TWO_REDUCTIONS       // A/B switch of tools/ (never defined in the shipped library)
     one_reduction = false;
 #else
@@ -140,10 +151,10 @@ template <> struct HelmholtzConsts<double> {         // fp64: table-driven e^{ik
     }
     __syncthreads();
     if (one_reduction) {
-      ck.set(ctx.v[0], -ctx.v[1], fastmath::TabCoeffs());
+      ck.set_scaled(ctx.v[0], -ctx.v[1], fastmath::TabCoeffs(), cdist);   // the one-reduction form reduces C r directly
       ck.pin();
     } else {
-      tk.set(ctx.v[0], -ctx.v[1], fastmath::TabCoeffs());
+      tk.set_scaled(ctx.v[0], -ctx.v[1], fastmath::TabCoeffs(), cdist);
       tk.pin();
     }
   }
@@ -160,8 +171,8 @@ template <> struct HelmholtzConsts<double> {         // fp64: table-driven e^{ik
   }
   __device__ __forceinline__ bool tile_bad(const KerCtx& ctx) const {
     const double rmax = __hiloint2double((int)(rmax_hi + 1u), 0);   // the next high word up bounds every low word
-    if (one_reduction) return !(ctx.v[0] * rmax <= fastmath::kCexpMaxPhase);
-    return !(__builtin_fabs(ctx.v[0]) * rmax <= fastmath::kSincosTabMaxArg && __builtin_fabs(ctx.v[1]) * rmax <= fastmath::kExpTabMaxArg);
+    if (one_reduction) return !(ctx.v[0] * rmax <= fastmath::kCexpMaxPhase * cdist);   // (the distances recorded are C r)
+    return !(__builtin_fabs(ctx.v[0]) * rmax <= fastmath::kSincosTabMaxArg * cdist && __builtin_fabs(ctx.v[1]) * rmax <= fastmath::kExpTabMaxArg * cdist);
   }
 };
 
@@ -198,6 +209,13 @@ template <class KC> __device__ __forceinline__ KC make_consts(double* lds, int l
   else return KC(lds);
 }
 template <class KC> __device__ __forceinline__ KC make_consts(double* lds, const KerCtx& ctx) { return make_consts<KC>(lds, KC::LDS_DOUBLES, ctx); }
+// ... and the accuracy mode of the launch, for a Consts type constructible from (double*, int, const KerCtx&, int mode): constants that depend on
+// which reciprocal square root pair() will use (HelmholtzConsts: the table reduction takes the distance as C r)
+template <class KC> __device__ __forceinline__ KC make_consts(double* lds, int lds_doubles, const KerCtx& ctx, int mode) {
+  if constexpr (std::is_constructible<KC, double*, int, const KerCtx&, int>::value) return KC(lds, lds_doubles, ctx, mode);
+  else return make_consts<KC>(lds, lds_doubles, ctx);
+}
+template <class KC> __device__ __forceinline__ KC make_consts(double* lds, const KerCtx& ctx, int mode) { return make_consts<KC>(lds, KC::LDS_DOUBLES, ctx, mode); }
 // Scratch the all-pairs evaluator offers a kernel: LDS_DOUBLES_ALL_PAIRS when the Consts type names one, LDS_DOUBLES otherwise.
 template <class KC, class = void> struct AllPairsScratch { static constexpr int value = KC::LDS_DOUBLES; };
 template <class KC> struct AllPairsScratch<KC, std::void_t<decltype(KC::LDS_DOUBLES_ALL_PAIRS)>> { static constexpr int value = KC::LDS_DOUBLES_ALL_PAIRS; };
@@ -489,6 +507,7 @@ struct Laplace3D_FDxUdU {
   template <class R, int MODE> static __device__ __forceinline__ void finish_mode(R (&acc)[K1]) { acc[0] *= R(rsqrt_scaled_c2(MODE)); }
 };
 
+static_assert(helmholtz_dist_factor(2) == rsqrt_scaled_factor(2, 1) && helmholtz_dist_factor(0) == 1, "HelmholtzConsts' distance factor is the cubic step's A");
 // ---- NEW: Helmholtz single layer G = exp(ikr)/r, complex k = ctx.v[0] + i ctx.v[1] (config 5)
 //   (u_re, u_im) += G (f_re, f_im) as complex numbers, scale 1/(4 pi), G = 0 at r = 0.
 struct Helmholtz3D_FxU {
@@ -496,7 +515,7 @@ struct Helmholtz3D_FxU {
   static constexpr const char* NAME = "Helmholtz3D-FxU";
   template <class R> using Consts = HelmholtzConsts<R>;
   static constexpr double scale() { return 1 / (4 * kPi); }
-  static constexpr double acc_factor(int /*mode*/) { return 1; }   // what pair() accumulates, relative to the kernel value
+  static constexpr double acc_factor(int mode) { return rsqrt_scaled_factor(mode, 1); }   // the amplitude is the mode's C / r
   template <class R> static __device__ __forceinline__ void pack(R* rec, const R* x, const R*, const R* f) {
     rec[0] = x[0]; rec[1] = x[1]; rec[2] = x[2]; rec[3] = f[0]; rec[4] = f[1]; rec[5] = 0;
   }
@@ -504,15 +523,16 @@ struct Helmholtz3D_FxU {
   template <class R, int MODE, bool MASKED, int VARIANT = 0> static __device__ __forceinline__ void pair(R (&acc)[K1], const R (&d)[3], const R* rec, const KerCtx& ctx, const Consts<R>& K) {
     constexpr bool REAL_K = (VARIANT & 1) != 0;
     const R r2 = len2(d);
-    const R rinv = rsqrt_masked<MODE, MASKED>(r2, K.rsq);
-    const R r = r2 * rinv;
+    const R rinv = rsqrt_scaled<MODE, MASKED>(r2, K.rsq);   // C / r: the amplitude, its C in the scale
+    const R rs = r2 * rinv;                                  // C r
     if constexpr ((VARIANT & 2) != 0) {
       R gr, gi;
-      cexp_<MASKED, REAL_K>(r, rinv, ctx, gr, gi, K);
+      cexp_<MASKED, REAL_K>(rs, rinv, ctx, gr, gi, K);        // reduces C r with the constants of k / C (HelmholtzConsts)
       acc[0] = fma_(gr, rec[3], fma_(-gi, rec[4], acc[0]));
       acc[1] = fma_(gi, rec[3], fma_(gr, rec[4], acc[1]));
       return;
     }
+    const R r = std::is_same<R, double>::value ? rs : rs * R(K.cinv);   // fp64: the table forms reduce C r with the constants of k / C; fp32 (hardware sine / cosine / exp2) takes r
     R sn, cs;
     sincos_<MASKED>(r, ctx, sn, cs, K);
     R amp = rinv;
@@ -523,11 +543,13 @@ struct Helmholtz3D_FxU {
   }
   // fp64, one reduction of r for the whole factor e^{ikr} (fastmath.hpp: cexp_tab_k); returns G = e^{ikr} / r.  The speculative pass runs it
   // unconditionally and records the largest distance; the careful pass branches per pair to libm beyond the table's range.
+  // (r is C r and rinv C / r here, C = K.cdist)
   template <bool MASKED, bool REAL_K> static __device__ __forceinline__ void cexp_(double r, double rinv, const KerCtx& ctx, double& gr, double& gi, const HelmholtzConsts<double>& K) {
-    if (MASKED && __builtin_expect(!(ctx.v[0] * r <= fastmath::kCexpMaxPhase), 0)) {
+    if (MASKED && __builtin_expect(!(ctx.v[0] * r <= fastmath::kCexpMaxPhase * K.cdist), 0)) {
       double s, c;
-      ::sincos(ctx.v[0] * r, &s, &c);
-      const double amp = REAL_K ? rinv : rinv * ::exp(-ctx.v[1] * r);
+      const double rt = r * K.cinv;
+      ::sincos(ctx.v[0] * rt, &s, &c);
+      const double amp = REAL_K ? rinv : rinv * ::exp(-ctx.v[1] * rt);
       gr = amp * c; gi = amp * s;
       return;
     }
@@ -554,8 +576,8 @@ struct Helmholtz3D_FxU {
       fastmath::sincos_tab_k(r, s, c, K.tk, K.table);
       return;
     }
-    const double x = ctx.v[0] * r;
-    if (__builtin_expect(__builtin_fabs(x) > fastmath::kSincosTabMaxArg, 0)) ::sincos(x, &s, &c);
+    const double x = ctx.v[0] * r;                       // (r is C r here: HelmholtzConsts)
+    if (__builtin_expect(__builtin_fabs(x) > fastmath::kSincosTabMaxArg * K.cdist, 0)) ::sincos(x * K.cinv, &s, &c);
     else fastmath::sincos_tab_k(r, s, c, K.tk, K.table);
   }
   // fp32: the hardware's sine / cosine / exp2 (v_sin_f32, v_cos_f32, v_exp_f32: ~1e-6 absolute, inputs in revolutions / powers of
@@ -576,7 +598,7 @@ struct Helmholtz3D_FxU {
     if (!MASKED) return fastmath::exp_tab_k(r, K.tk, K.table);   // range checked at the end of the tile (tile_bad)
     // careful pass: r >= 0 clamped to kExpTabMaxArg / |Im k| — the value there is 0 or inf already (a NaN distance turns into the cap, but
     // then rinv is NaN too and the product stays NaN)
-    return fastmath::exp_tab_k(__builtin_fmin(r, fastmath::kExpTabMaxArg / __builtin_fabs(ctx.v[1])), K.tk, K.table);
+    return fastmath::exp_tab_k(__builtin_fmin(r, fastmath::kExpTabMaxArg * K.cdist / __builtin_fabs(ctx.v[1])), K.tk, K.table);
   }
   template <bool MASKED> static __device__ __forceinline__ float exp_(float r, const KerCtx& ctx, const HelmholtzConsts<float>&) {
     const float x = -float(ctx.v[1]) * r;
