@@ -2,6 +2,7 @@
 // (rocPRIM radix sort of 63-bit keys), evaluate on the sorted order, scatter-add the result back.  Everything is enqueued
 // on the caller's stream; temporaries are carved out of the stream's scratch block (workspace.hpp).
 #include "centered_kernel.hpp"
+#include "centered_mfma_kernel.hpp"
 #include <sctl_amd/device/launch.hpp>
 #include "workspace.hpp"
 
@@ -18,7 +19,19 @@ namespace sctl_amd {
   } while (0)
 
 namespace {
+// fp32 Laplace single layer at the seed's accuracy takes the kernel whose r^2 comes from the bf16 matrix cores (centered_mfma_kernel.hpp);
+// SCTL_AMD_MFMA_F32=0 keeps the packed-VALU kernel (A/B runs and tests that compare the two)
+bool use_mfma_f32() {
+  const char* e = std::getenv("SCTL_AMD_MFMA_F32");
+  return !(e && e[0] == '0');
+}
 template <class CP, class R, int MODE> void launch_centered(const EvalArgs<R>& a, dim3 grid, hipStream_t st) {
+  if constexpr (std::is_same<R, float>::value && std::is_same<CP, CenteredFxU<float>>::value && MODE == 0) {
+    if (use_mfma_f32()) {
+      hipLaunchKernelGGL(centered_mfma_fxu_f32_kernel, grid, dim3(kWaveBlock), 0, st, a);
+      return;
+    }
+  }
 #if defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_FAR_UNR)   // A/B builds: far records per unrolled group
   hipLaunchKernelGGL((centered_kernel<CP, R, MODE, 2, SCTL_AMD_EXP_FAR_UNR>), grid, dim3(kWaveBlock), 0, st, a);
 #else

@@ -157,3 +157,29 @@ def test_one_process_multi_device_slabs_follow_the_morton_curve(O):
         assert rel_l2(u, one) <= 1e-13
     three32 = sctl_amd.eval_host("Laplace3D-FxU", xt.astype(np.float32), xs.astype(np.float32), None, f.astype(np.float32), devices=[0, 0, 0])
     assert rel_l2(three32[sel].astype(np.float64), ref) <= 1e-4
+
+
+@pytest.mark.parametrize("kind", ["uniform", "clustered", "surface", "identical_targets", "offset"])
+def test_centred_fp32_distance_on_the_matrix_cores_matches_the_packed_valu_kernel(O, kind):
+    """fp32 Laplace single layer: the kernel whose far-pair r^2 is a split-bf16 contraction on the matrix cores (centered_mfma_kernel.hpp, the
+    default) against the packed-VALU kernel (SCTL_AMD_MFMA_F32=0) and the fp64 oracle on the same fp32-rounded inputs, on the point clouds that
+    stress the far / near split; ragged sizes, so the last target tile, the last source tile and the carried leftovers are exercised."""
+    import torch
+    rng = np.random.default_rng(321)
+    xt, xs = _clouds(kind, rng)
+    xt, xs = np.ascontiguousarray(xt.ravel()).astype(np.float32), np.ascontiguousarray(xs.ravel()).astype(np.float32)
+    f = (rng.random(NS) - 0.5).astype(np.float32)
+    assert sctl_amd.plan("Laplace3D-FxU", 1, NT, NS)["path"] == "tile-centred"
+    d = [torch.from_numpy(a).cuda() for a in (xt, xs, f)]
+    u = sctl_amd.eval_device("Laplace3D-FxU", d[0], d[1], None, d[2]).cpu().numpy()
+    assert np.all(np.isfinite(u))
+    os.environ["SCTL_AMD_MFMA_F32"] = "0"
+    try:
+        u_valu = sctl_amd.eval_device("Laplace3D-FxU", d[0], d[1], None, d[2]).cpu().numpy()
+    finally:
+        del os.environ["SCTL_AMD_MFMA_F32"]
+    sel = rng.choice(NT, 300, replace=False)
+    ref = O.eval("Laplace3D-FxU", xt.reshape(NT, 3)[sel].astype(np.float64).ravel().copy(), xs.astype(np.float64), None, f.astype(np.float64))
+    e_m, e_v = rel_l2(u[sel], ref), rel_l2(u_valu[sel], ref)
+    assert e_m <= 1e-4 and e_m <= 3 * e_v + 1e-6, (kind, e_m, e_v)
+    assert rel_l2(u, u_valu) <= 2e-5, (kind, rel_l2(u, u_valu))
