@@ -315,6 +315,12 @@ int sctl_amd_eval_plan(int kernel, int real, int64_t Nt, int64_t Ns, int64_t Nt_
  * Negative = error code.  Setting SCTL_AMD_CENTERED=0 in the environment forces 0. */
 int sctl_amd_eval_path(int kernel, int real, int64_t Nt, int64_t Ns, int64_t Nt_whole);
 
+/* Which execution units the far pairs of that problem run on at `digits` (for roofline labels; no side effects): 0 = the vector pipe, exact kernel;
+ * 1 = the vector pipe, tile-centred path; 2 = tile-centred path with r2 as a split-bf16 contraction on the MATRIX cores (v_mfma_f32_32x32x16_bf16)
+ * and v_rsq_f32 + the accumulation on the vector pipe — fp32 Laplace3D-FxU at the seed's accuracy (digits < 8); SCTL_AMD_MFMA_F32=0 in the
+ * environment keeps such problems on 1.  Negative = error code.  (The reference has one pipe, the host's SIMD units: vec.hpp.) */
+int sctl_amd_eval_pipe(int kernel, int real, int64_t Nt, int64_t Ns, int64_t Nt_whole, int digits);
+
 #ifdef __cplusplus
 }
 #endif

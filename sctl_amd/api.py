@@ -23,7 +23,7 @@ KERNEL_NAMES = ["Laplace3D-FxU", "Laplace3D-DxU", "Laplace3D-FxdU", "Stokes3D-Fx
 SYMBOLS = ["sctl_amd_version", "sctl_amd_last_error", "sctl_amd_device_count", "sctl_amd_init", "sctl_amd_finalize", "sctl_amd_kernel_id", "sctl_amd_kernel_name",
            "sctl_amd_kernel_info", "sctl_amd_flops_per_pair", "sctl_amd_eval_device", "sctl_amd_eval_device_slab", "sctl_amd_eval_host", "sctl_amd_eval_host_multi",
            "sctl_amd_kernel_matrix_device", "sctl_amd_kernel_matrix_host", "sctl_amd_kernel_matrix_batch_host", "sctl_amd_counters", "sctl_amd_reset_counters", "sctl_amd_trim",
-           "sctl_amd_eval_plan", "sctl_amd_eval_path", "sctl_amd_op_create", "sctl_amd_op_set_targets",
+           "sctl_amd_eval_plan", "sctl_amd_eval_path", "sctl_amd_eval_pipe", "sctl_amd_op_create", "sctl_amd_op_set_targets",
            "sctl_amd_op_set_sources", "sctl_amd_op_set_source_weights", "sctl_amd_op_set_target_normals", "sctl_amd_op_eval", "sctl_amd_op_destroy", "sctl_amd_near_create", "sctl_amd_near_apply_host",
            "sctl_amd_near_apply_device", "sctl_amd_near_info", "sctl_amd_near_destroy", "sctl_amd_num_kernels", "sctl_amd_register_kernel", "sctl_amd_load_plugin",
            "sctl_amd_set_debug", "sctl_amd_comm_create", "sctl_amd_comm_info", "sctl_amd_comm_allgatherv_host", "sctl_amd_comm_barrier", "sctl_amd_comm_selftest", "sctl_amd_comm_destroy",
@@ -96,6 +96,7 @@ def lib():
     L.sctl_amd_near_destroy.restype = None
     L.sctl_amd_eval_plan.argtypes = [ci, ci, i64, i64, i64, ci, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(i64), C.POINTER(i64)]
     L.sctl_amd_eval_path.argtypes = [ci, ci, i64, i64, i64]
+    L.sctl_amd_eval_pipe.argtypes = [ci, ci, i64, i64, i64, ci]
     L.sctl_amd_op_create.argtypes = [ci, ci, C.POINTER(C.c_int), ci, C.POINTER(vp)]
     L.sctl_amd_op_set_targets.argtypes = [vp, i64, vp]
     L.sctl_amd_op_set_sources.argtypes = [vp, i64, vp, vp]
@@ -195,8 +196,10 @@ def plan(name, real, Nt, Ns, digits=-1, nt_whole=0):
     wg, ws = C.c_int64(), C.c_int64()
     _check(lib().sctl_amd_eval_plan(kernel_id(name), real, Nt, Ns, nt_whole, digits, C.byref(t), C.byref(s), C.byref(wg), C.byref(ws)), "eval_plan")
     path = lib().sctl_amd_eval_path(kernel_id(name), real, Nt, Ns, nt_whole)
+    pipe = lib().sctl_amd_eval_pipe(kernel_id(name), real, Nt, Ns, nt_whole, digits)
     return dict(trg_per_lane=t.value, src_splits=s.value, workgroups=wg.value, workspace_bytes=ws.value,
-                path="tile-centred" if path == 1 else "exact")
+                path="tile-centred" if path == 1 else "exact",
+                pipe="bf16 matrix cores (r^2) + vector pipe (rsqrt, accumulate)" if pipe == 2 else "vector pipe")
 
 
 def counters():

@@ -27,6 +27,8 @@ template <class R>
 hipError_t eval_centered(int kernel_id, int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* xn, const R* f, R* v_trg, double scale, int mode,
                          int cus, hipStream_t st, bool presorted);
 void centered_plan(int64_t Nt, int64_t Ns, int cus, int src_bytes, int* T, int* splits, int64_t* chunk);
+int centered_pipe(int kernel_id, int real, int mode);
+int centered_targets_per_wave(int kernel_id, int real, int mode);
 hipError_t morton_order_device(int real, const void* d_x, int64_t n, void* d_sorted, uint32_t* d_perm, hipStream_t st);   // centered.hip
 namespace {
 
@@ -1277,7 +1279,6 @@ int sctl_amd_set_debug(int flags) {
 
 int sctl_amd_eval_plan(int kernel, int real, int64_t Nt, int64_t Ns, int64_t Nt_whole, int digits, int* trg_per_lane, int* src_splits,
                        int64_t* workgroups, int64_t* workspace_bytes) {
-  (void)digits;
   const KernelEntry* k = registry(kernel);
   if (!k) return fail(SCTL_AMD_ERR_UNKNOWN_KERNEL, "unknown kernel id");
   if (real != SCTL_AMD_F64 && real != SCTL_AMD_F32) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "real must be SCTL_AMD_F64 or SCTL_AMD_F32");
@@ -1286,9 +1287,11 @@ int sctl_amd_eval_plan(int kernel, int real, int64_t Nt, int64_t Ns, int64_t Nt_
     int T, splits;
     int64_t chunk;
     centered_plan(Nt, Ns, cu_count(), (real == SCTL_AMD_F64 ? 8 : 4) * (3 + k->nd + k->k0), &T, &splits, &chunk);
-    if (trg_per_lane) *trg_per_lane = T;
+    const int64_t per_wave = centered_targets_per_wave(k->id, real, mode_for(real, digits));   // 128, or 256 for the matrix-core double layer (centered.hip)
+    (void)T;
+    if (trg_per_lane) *trg_per_lane = (int)(per_wave / 64);
     if (src_splits) *src_splits = splits;
-    if (workgroups) *workgroups = ((Nt + 64 * T - 1) / (64 * T)) * splits;   // one wave64 per workgroup
+    if (workgroups) *workgroups = ((Nt + per_wave - 1) / per_wave) * splits;   // one wave64 per workgroup
     if (workspace_bytes) *workspace_bytes = (splits > 1) ? (int64_t)splits * Nt * (real == SCTL_AMD_F64 ? 8 : 4) : 0;
     return SCTL_AMD_OK;
   }
@@ -1305,6 +1308,12 @@ int sctl_amd_eval_path(int kernel, int real, int64_t Nt, int64_t Ns, int64_t Nt_
   if (!k) return fail(SCTL_AMD_ERR_UNKNOWN_KERNEL, "unknown kernel id");
   if (real != SCTL_AMD_F64 && real != SCTL_AMD_F32) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "real must be SCTL_AMD_F64 or SCTL_AMD_F32");
   return use_centered(*k, real, Nt, Ns, Nt_whole) ? 1 : 0;
+}
+
+int sctl_amd_eval_pipe(int kernel, int real, int64_t Nt, int64_t Ns, int64_t Nt_whole, int digits) {
+  const int path = sctl_amd_eval_path(kernel, real, Nt, Ns, Nt_whole);
+  if (path <= 0) return path;
+  return centered_pipe(registry(kernel)->id, real, mode_for(real, digits));
 }
 
 }  // extern "C"

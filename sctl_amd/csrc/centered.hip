@@ -19,16 +19,36 @@ namespace sctl_amd {
   } while (0)
 
 namespace {
-// fp32 Laplace single layer at the seed's accuracy takes the kernel whose r^2 comes from the bf16 matrix cores (centered_mfma_kernel.hpp);
-// SCTL_AMD_MFMA_F32=0 keeps the packed-VALU kernel (A/B runs and tests that compare the two)
+// fp32 Laplace single and double layer at the seed's accuracy take the kernel whose contractions run on the bf16 matrix cores
+// (centered_mfma_kernel.hpp); SCTL_AMD_MFMA_F32=0 keeps the packed-VALU kernel (A/B runs and tests that compare the two)
 bool use_mfma_f32() {
   const char* e = std::getenv("SCTL_AMD_MFMA_F32");
   return !(e && e[0] == '0');
 }
+}  // namespace
+// 2 when the tile-centred path of (kernel, real, mode) takes its far distances from the bf16 matrix cores, 1 when it runs on the vector pipe alone
+// (what sctl_amd_eval_pipe reports; must say what launch_centered does)
+int centered_pipe(int kernel_id, int real, int mode) {
+  return ((kernel_id == Laplace3D_FxU::ID || kernel_id == Laplace3D_DxU::ID) && real == 1 /* SCTL_AMD_F32 */ && mode == 0 && use_mfma_f32()) ? 2 : 1;
+}
+// Targets per wave (= per workgroup) of that path: 128 (two per lane), or 256 = eight 32-column blocks for the matrix-core double layer, whose per-tile
+// staging (two contraction rows per source) is then shared by twice the pairs: 745 -> 675 ms at 2^21, where the single layer loses (445 -> 470 ms: more
+// near sources per wave, fewer waves per SIMD); A/B on one box, profiles/r03_ab_mfma_variants.txt.  SCTL_AMD_MFMA_CB=4 / 8 overrides (A/B runs).
+int centered_targets_per_wave(int kernel_id, int real, int mode) {
+  if (centered_pipe(kernel_id, real, mode) != 2) return 128;
+  if (const char* e = std::getenv("SCTL_AMD_MFMA_CB")) {
+    if (e[0] == '8') return 256;
+    if (e[0] == '4') return 128;
+  }
+  return kernel_id == Laplace3D_DxU::ID ? 256 : 128;
+}
+namespace {
 template <class CP, class R, int MODE> void launch_centered(const EvalArgs<R>& a, dim3 grid, hipStream_t st) {
-  if constexpr (std::is_same<R, float>::value && std::is_same<CP, CenteredFxU<float>>::value && MODE == 0) {
-    if (use_mfma_f32()) {
-      hipLaunchKernelGGL(centered_mfma_fxu_f32_kernel, grid, dim3(kWaveBlock), 0, st, a);
+  if constexpr (std::is_same<R, float>::value && MODE == 0) {
+    if (use_mfma_f32()) {   // (the caller sized grid.x with centered_targets_per_wave)
+      constexpr bool DL = std::is_same<CP, CenteredDxU<float>>::value;
+      if (centered_targets_per_wave(CP::Ker::ID, 1, 0) == 256) hipLaunchKernelGGL((centered_mfma_f32_kernel<DL, 8>), grid, dim3(kWaveBlock), 0, st, a);
+      else hipLaunchKernelGGL((centered_mfma_f32_kernel<DL, 4>), grid, dim3(kWaveBlock), 0, st, a);
       return;
     }
   }
@@ -86,7 +106,8 @@ hipError_t eval_centered_t(int64_t Nt, int64_t Ns, const R* xt, const R* xs, con
     a.Nt = Nt; a.Ns = Ns; a.xt = xt; a.xs = xs; a.xn = xn; a.f = f; a.v_trg = v_trg; a.partial = partial;
     a.chunk = chunk; a.scale = scale;
     a.ctx.v[0] = kNearFactor2;
-    const dim3 grid((unsigned)((Nt + (int64_t)kWaveBlock * T - 1) / ((int64_t)kWaveBlock * T)), (unsigned)splits);
+    const int64_t per_wave = centered_targets_per_wave(CP::Ker::ID, sizeof(R) == 8 ? 0 : 1, mode);
+    const dim3 grid((unsigned)((Nt + per_wave - 1) / per_wave), (unsigned)splits);
     if (mode == 0) launch_centered<CP, R, 0>(a, grid, st);
     else if (mode == 1) launch_centered<CP, R, 1>(a, grid, st);
     else launch_centered<CP, R, (sizeof(R) == 8 ? 2 : 1)>(a, grid, st);
@@ -129,7 +150,8 @@ hipError_t eval_centered_t(int64_t Nt, int64_t Ns, const R* xt, const R* xs, con
   if (const char* e = std::getenv("SCTL_AMD_EXPERIMENT_NEAR_FACTOR")) a.ctx.v[0] = std::atof(e);
 #endif
   a.partial = partial;
-  const dim3 grid((unsigned)((Nt + (int64_t)kWaveBlock * T - 1) / ((int64_t)kWaveBlock * T)), (unsigned)splits);
+  const int64_t per_wave = centered_targets_per_wave(CP::Ker::ID, sizeof(R) == 8 ? 0 : 1, mode);
+  const dim3 grid((unsigned)((Nt + per_wave - 1) / per_wave), (unsigned)splits);
   if (mode == 0) launch_centered<CP, R, 0>(a, grid, st);
   else if (mode == 1) launch_centered<CP, R, 1>(a, grid, st);
   else launch_centered<CP, R, (sizeof(R) == 8 ? 2 : 1)>(a, grid, st);

@@ -66,7 +66,12 @@ template <> struct Rec4<float> {
 // the 4x larger L2 read volume (every wave streams all sources: 0.6 TB/s at 2^20) is far below the L2's bandwidth.
 constexpr int kWaveBlock = 64;   // lanes per workgroup of the centred kernel
 constexpr int kWaveTile = 64;    // sources per LDS tile
+#if defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_NEARCAP)   // debugging builds
+constexpr int kNearCap = SCTL_AMD_EXP_NEARCAP;   // >= kWaveTile: one tile may bring that many near sources
+static_assert(kNearCap >= 64, "a tile of 64 sources must fit the list of pending near sources");
+#else
 constexpr int kNearCap = 128;    // capacity of the per-wave list of pending near sources
+#endif
 
 // fp32 with two targets per lane: the two targets' far pairs as ONE stream of packed instructions.  gfx950 issues v_pk_fma_f32 (two
 // FMAs per lane) at the cost of one fp64 FMA, where two v_fma_f32 cost 1.3 (tools/ubench/valu_rates: 2.96 vs 2 x 1.93 cycles per
@@ -320,6 +325,19 @@ __global__ void __launch_bounds__(kWaveBlock) SCTL_AMD_CENTERED_ATTR centered_ke
         for (int j = 0; j < T; j++) {
           const R d[3] = {xo[j][0] - q[0], xo[j][1] - q[1], xo[j][2] - q[2]};
           Ker::template pair<R, MODE, true>(acc[j], d, q, a.ctx, K);
+          // One pair after the other, never interleaved.  MEASURED on gfx950 (round 3, ROCm 7.2): the matrix-core double-layer kernel with 128 targets per
+          // wave (centered_mfma_kernel.hpp) gave near sums that differed from RUN TO RUN — lanes 48-63, the first of the lane's targets, only in waves that
+          // flush their near list between tiles; 7 000 of 2^18 targets, errors up to O(1) — while its far sums and, in builds that kept only one of the two,
+          // each sum alone were bit-stable.  With the two targets' pairs interleaved hipcc had emitted `v_rsq_f32 v34, v36` directly followed by
+          // `v_pk_mul_f32 v[36:37], ...`: the next instruction overwrites the transcendental's source, and the wrong values are those that come from that
+          // v_rsq.  With this fence the pattern is gone and every result is bit-identical run to run (tools/near_determinism.py: with / without the fence,
+          // near list of 64 / 128, profiles/r03_near_determinism.txt).  NOT isolated: the bare instruction pair in a microbenchmark
+          // (tools/ubench/trans_war.hip) and the packed-VALU double-layer kernel here, which carried the same pair, do not show it — the pair is necessary in
+          // what was seen, not sufficient.  tools/check_mfma_operands.py looks for it in the assembly of every build (tests/test_boundary.py), and
+          // tests/test_gpu_centered.py asks for bit-identical repeats.
+#if !(defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_NO_NEAR_FENCE))   // (the A/B build of tools/near_determinism.py)
+          __builtin_amdgcn_sched_barrier(0);
+#endif
         }
       }
     }

@@ -1,17 +1,22 @@
-// fp32 Laplace single layer on the tile-centred path with the far pairs' r^2 on the bf16 MATRIX cores.
+// fp32 Laplace single and double layer on the tile-centred path with the far pairs' contractions on the bf16 MATRIX cores.
 //
-// Why: the fp32 far loop of centered_kernel.hpp costs ~19 issue cycles per wave-pair, 8 of them the packed-fp32 distance
+// Why: the fp32 far loop of centered_kernel.hpp costs ~19 issue cycles per wave-pair (single layer), 8 of them the packed-fp32 distance
 // r2 = |x_t'|^2 + |x_s'|^2 - 2 x_t'.x_s' and 8 the v_rsq_f32.  fp32-input MFMA shares the fp32 VALU's pipe on gfx950 (tools/ubench/f32_mfma_mix.hip), but the
 // bf16 matrix cores do not: a v_mfma_f32_32x32x16_bf16 holds the SIMD's vector issue for 8 of its 32 cycles (MI355X_MICROARCH.md) and v_rsq_f32 runs beside
 // it (tools/ubench/bf16_mfma_mix.hip, profiles/r03_ubench_bf16_mfma_mix.txt: 14.2 against 25.7 cycles per wave-pair for the loop bodies).  So r2 becomes a genuine dense
-// contraction, in split precision: every centred coordinate is cut into three bf16 pieces (x = a1 + a2 + a3 exactly: 3 x 8 bits = fp32's 24), and
-//     r2(s, t) = sum_k A[s][k] B[k][t],   K = 24 (padded to 32):
-//         per coordinate  A = [a1, a1, a2, a1, a2, a3],  B = -2 [b1, b2, b1, b3, b2, b1]     (the six piece products down to 2^-16; the rest is below 2^-24)
-//         |x_s'|^2        A = [s1, s2, s3],               B = [1, 1, 1]
-//         |x_t'|^2        A = [1, 1, 1],                  B = [t1, t2, t3]
-// with exact bf16 products and fp32 accumulation inside the MFMA: the same ~2^-21 relative accuracy (after the far condition's cancellation bound) as the
+// contraction, in split precision: every centred coordinate is cut into three bf16 pieces, x = a1 + a2 + a3 EXACTLY (3 x 8 bits = fp32's 24; the pieces are
+// the high halves of x, x - a1 and x - a1 - a2, i.e. cut by truncation: one v_and + one v_sub each), and
+//     r2(s, t) = sum_k A[s][k] B[k][t],   K = 30 (padded to 32):
+//         per coordinate  A = [a1, a1, a1, a2, a2, a3, a2, a3],  B = -2 x_t' as [b1, b2, b3, b1, b2, b1, b3, b2]   (every piece product but a3 b3 < 2^-28 |a||b|)
+//         |x_s'|^2        A = [s1, s2, s3],                       B = [1, 1, 1]
+//         |x_t'|^2        A = [1, 1, 1],                          B = [t1, t2, t3]
+// with exact bf16 products and fp32 accumulation inside the MFMA: the ~2^-21 relative accuracy (after the far condition's cancellation bound) of the
 // four fp32 FMAs it replaces.  Two MFMAs (K = 2 x 16) give the r2 of 32 sources x 32 targets; lane l holds 16 of them — target column l % 32, source rows
-// 8 k + 4 (l / 32) + {0..3} — as registers, takes v_rsq_f32 of each and accumulates f_s / r with v_pk_fma_f32, the densities of its 16 rows read from LDS.
+// 8 k + 4 (l / 32) + {0..3} — as registers, takes v_rsq_f32 of each and accumulates with v_pk_fma_f32.
+//   single layer: acc += f_s / r, the densities of the lane's 16 rows read from LDS;
+//   double layer: ((x_t - x_s).n_s f_s) / r^3.  The numerator is a SECOND contraction against the SAME B operand: (x_t' - x_s').nf =
+//         sum over coordinates of (-nf/2)(-2 x_t') - x_s'.nf, i.e. a row A2 with the pieces of -nf_c / 2 in the coordinate slots, those of -x_s'.nf in the
+//         |x_s'|^2 slots and zeros in the |x_t'|^2 slots: two more MFMAs per 32 x 32 pairs, and the VALU is left with v_rsq_f32, y^3 and one FMA per pair.
 // A wave owns 128 targets as four column blocks (their B operands stay in registers for the whole kernel); the two half-waves see different source rows
 // of the same targets and add their sums at the end.  Staging, the far / near split, the exact masked near path, the carry of leftover far sources and
 // the (tile, split) mapping are those of centered_kernel.hpp.  fp32, MODE 0 only (more digits than the seed's go through the VALU kernel).
@@ -26,50 +31,39 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kMfmaRows = 32;    // far sources per MFMA row block
-constexpr int kRowWords = 5;     // 16-byte LDS words per far row: four of bf16 pieces (K = 32) + one of padding (spreads the rows over the banks)
-constexpr int kColBlocks = 4;    // column blocks of 32 targets per wave: 128 targets, as the VALU kernel with two targets per lane
 
-// x = p[0] + p[1] + p[2], each piece rounded to nearest: exact for an fp32 x up to its last bit
-__device__ __forceinline__ void split3(float x, __bf16 (&p)[3]) {
-  p[0] = (__bf16)x;
-  float r = x - (float)p[0];
-  p[1] = (__bf16)r;
-  r -= (float)p[1];
-  p[2] = (__bf16)r;
+// two bf16 K-entries as one register: the HIGH halves of two floats (entry k in the low 16 bits, entry k + 1 in the high 16) — one v_perm_b32; taking
+// the high half IS the truncation to bf16
+__device__ __forceinline__ unsigned hi2(float e0, float e1) { return __builtin_amdgcn_perm(__float_as_uint(e1), __float_as_uint(e0), 0x07060302u); }
+// x = hi(x) + hi(r1) + hi(r2) exactly, hi() = the float with the low 16 bits cleared: r1 = x - hi(x) has at most 16 significant bits, r2 = r1 - hi(r1) at most 8
+__device__ __forceinline__ void split3(float x, float& r1, float& r2) {
+  r1 = x - __uint_as_float(__float_as_uint(x) & 0xffff0000u);
+  r2 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
 }
-__device__ __forceinline__ u32x4 word_of(const __bf16* e) {
-  bf16x8 v;
-#pragma unroll
-  for (int i = 0; i < 8; i++) v[i] = e[i];
-  return __builtin_bit_cast(u32x4, v);
+// the eight K-entries of one coordinate: A side [a1, a1, a1, a2, a2, a3, a2, a3], B side [b1, b2, b3, b1, b2, b1, b3, b2]
+__device__ __forceinline__ u32x4 a_word(float x) {
+  float r1, r2;
+  split3(x, r1, r2);
+  const unsigned w = hi2(r1, r2);
+  return u32x4{hi2(x, x), hi2(x, r1), w, w};
 }
-// the 24 A entries of a source (K order of the header comment); entries 24..31 are zero and never written
-__device__ __forceinline__ void source_row(const float (&p)[3], float ss, __bf16 (&e)[24]) {
-#pragma unroll
-  for (int c = 0; c < 3; c++) {
-    __bf16 a[3];
-    split3(p[c], a);
-    e[6 * c] = a[0]; e[6 * c + 1] = a[0]; e[6 * c + 2] = a[1]; e[6 * c + 3] = a[0]; e[6 * c + 4] = a[1]; e[6 * c + 5] = a[2];
-  }
-  __bf16 s[3];
-  split3(ss, s);
-  e[18] = s[0]; e[19] = s[1]; e[20] = s[2];
-  e[21] = e[22] = e[23] = (__bf16)1.0f;
+__device__ __forceinline__ u32x4 b_word(float x) {
+  float r1, r2;
+  split3(x, r1, r2);
+  return u32x4{hi2(x, r1), hi2(r2, x), hi2(r1, x), hi2(r2, r1)};
 }
-// the 32 B entries of a target
-__device__ __forceinline__ void target_col(const float (&p)[3], float tt, __bf16 (&e)[32]) {
-#pragma unroll
-  for (int c = 0; c < 3; c++) {
-    __bf16 b[3];
-    split3(-2.0f * p[c], b);       // (-2 x exactly: a power of two)
-    e[6 * c] = b[0]; e[6 * c + 1] = b[1]; e[6 * c + 2] = b[0]; e[6 * c + 3] = b[2]; e[6 * c + 4] = b[1]; e[6 * c + 5] = b[0];
-  }
-  e[18] = e[19] = e[20] = (__bf16)1.0f;
-  __bf16 t[3];
-  split3(tt, t);
-  e[21] = t[0]; e[22] = t[1]; e[23] = t[2];
-#pragma unroll
-  for (int k = 24; k < 32; k++) e[k] = (__bf16)0.0f;
+constexpr unsigned kOnes2 = 0x3f803f80u;   // {1, 1} in bf16
+// the last word of a row: the source side carries [v1, v2, v3, u, u, u, 0, 0] (u = 1 for the r2 row, 0 for the double layer's numerator row) ...
+__device__ __forceinline__ u32x4 a_tail(float v, bool ones) {
+  float r1, r2;
+  split3(v, r1, r2);
+  return u32x4{hi2(v, r1), hi2(r2, ones ? 1.0f : 0.0f), ones ? kOnes2 : 0u, 0u};
+}
+// ... and the target side [1, 1, 1, t1, t2, t3, 0, 0]
+__device__ __forceinline__ u32x4 b_tail(float tt) {
+  float r1, r2;
+  split3(tt, r1, r2);
+  return u32x4{kOnes2, hi2(1.0f, tt), hi2(r1, r2), 0u};
 }
 
 // a.xt: Morton-sorted targets; a.v_trg / a.partial indexed like a.xt (as centered_kernel)
@@ -78,13 +72,19 @@ __device__ __forceinline__ void target_col(const float (&p)[3], float tt, __bf16
 #else
 #define SCTL_AMD_MFMA_ATTR
 #endif
-__global__ void __launch_bounds__(kWaveBlock) SCTL_AMD_MFMA_ATTR centered_mfma_fxu_f32_kernel(const EvalArgs<float> a) {
+// CB: column blocks of 32 targets per wave (4: 128 targets, as the VALU kernel with two targets per lane)
+template <bool DL, int CB> __global__ void __launch_bounds__(kWaveBlock) SCTL_AMD_MFMA_ATTR centered_mfma_f32_kernel(const EvalArgs<float> a) {
   using R = float;
-  using Ker = Laplace3D_FxU;
+  constexpr int kColBlocks = CB, NQ = CB / 2;   // NQ: targets a lane owns (column blocks NQ h .. NQ h + NQ - 1)
+  using Ker = typename std::conditional<DL, Laplace3D_DxU, Laplace3D_FxU>::type;
   using V = Rec4<R>::V;   // float4
-  __shared__ u32x4 farA[(kWaveTile + kMfmaRows) * kRowWords];   // A rows of the far sources (+ the leftovers of earlier tiles)
-  __shared__ f32x4 farF4[(kWaveTile + kMfmaRows) / 4];            // their densities
-  __shared__ V nearA[kNearCap + 2];                              // packed exact records {x, y, z, f} of the pending near sources
+  constexpr int ND = Ker::ND;
+  constexpr int NEARW = (Ker::NREC + 3) / 4;   // 16-byte words of a near record (the kernel's packed exact record)
+  constexpr int RW = DL ? 9 : 5;               // 16-byte LDS words per far row: four per contraction row (K = 32) + one of padding (spreads the rows over the banks)
+  constexpr int kRowsCap = kWaveTile + kMfmaRows;
+  __shared__ u32x4 farA[kRowsCap * RW];                   // rows of the far sources (+ the leftovers of earlier tiles): A, then (double layer) A2
+  __shared__ f32x4 farF4[DL ? 1 : kRowsCap / 4];          // single layer: their densities
+  __shared__ V nearA[(kNearCap + 2) * NEARW];             // packed exact records of the pending near sources
   float* const farF = (float*)farF4;
 
   const int lane = threadIdx.x, m = lane & 31, h = lane >> 5;
@@ -94,11 +94,8 @@ __global__ void __launch_bounds__(kWaveBlock) SCTL_AMD_MFMA_ATTR centered_mfma_f
     tile_idx = j % gridDim.x;
     split_idx = xcd * per + j / gridDim.x;
   }
-  const int64_t tbase = (int64_t)tile_idx * (kWaveBlock * 2);
-  const Ker::Consts<R> K(nullptr);
-
-  // words 3 (K entries 24..31: zero) and 4 (padding) of every far row, once
-  for (int r = lane; r < kWaveTile + kMfmaRows; r += kWaveBlock) { farA[r * kRowWords + 3] = u32x4{0, 0, 0, 0}; farA[r * kRowWords + 4] = u32x4{0, 0, 0, 0}; }
+  const int64_t tbase = (int64_t)tile_idx * (32 * CB);
+  const typename Ker::template Consts<R> K(nullptr);
 
   // ---- this lane's four B-operand targets (column m of each block), cluster centre and radius ------------------------
   R xb[kColBlocks][3], c[3];
@@ -125,32 +122,36 @@ __global__ void __launch_bounds__(kWaveBlock) SCTL_AMD_MFMA_ATTR centered_mfma_f
     const R p[3] = {xb[cb][0] - c[0], xb[cb][1] - c[1], xb[cb][2] - c[2]};
     const R tt = len2(p);
     rt2 = (tt > rt2) ? tt : rt2;
-    __bf16 e[32];
-    target_col(p, tt, e);
+    const u32x4 w[4] = {b_word(-2.0f * p[0]), b_word(-2.0f * p[1]), b_word(-2.0f * p[2]), b_tail(tt)};   // (-2 x exactly: a power of two)
 #pragma unroll
     for (int step = 0; step < 2; step++) {
-      const u32x4 w0 = word_of(e + 16 * step), w1 = word_of(e + 16 * step + 8);
 #pragma unroll
-      for (int i = 0; i < 4; i++) Bop[cb][step][i] = h ? w1[i] : w0[i];
+      for (int i = 0; i < 4; i++) Bop[cb][step][i] = h ? w[2 * step + 1][i] : w[2 * step][i];
     }
   }
   rt2 = uniform_(wave_max(rt2));
   const R near_r2 = R(a.ctx.v[0]) * rt2;   // NaN coordinates fail every comparison => "near" => exact path
 
-  R acc[kColBlocks] = {0, 0, 0, 0};   // far sums of this half-wave's source rows, per column block
-  R accn[2][1] = {{0}, {0}};          // near sums of the two targets this lane owns: column blocks 2 h and 2 h + 1
+  R acc[kColBlocks];   // far sums of this half-wave's source rows, per column block
+#pragma unroll
+  for (int cb = 0; cb < kColBlocks; cb++) acc[cb] = 0;
+  R accn[NQ][1];       // near sums of the targets this lane owns
+#pragma unroll
+  for (int q = 0; q < NQ; q++) accn[q][0] = 0;
 
   const int64_t s_begin = (int64_t)split_idx * a.chunk;
   const int64_t s_end = (s_begin + a.chunk < a.Ns) ? s_begin + a.chunk : a.Ns;
   const int64_t len = (s_end > s_begin) ? s_end - s_begin : 0;
   const int ntile = (int)((len + kWaveTile - 1) / kWaveTile);
 
-  R x[3] = {0, 0, 0}, f[1] = {0};
+  R x[3] = {0, 0, 0}, nrm[3] = {0, 0, 0}, f[1] = {0};
   auto load_source = [&](int it) {
     const int64_t s = s_begin + (int64_t)it * kWaveTile + lane;
     if (s < s_end) {
 #pragma unroll
       for (int k = 0; k < 3; k++) x[k] = a.xs[s * 3 + k];
+#pragma unroll
+      for (int k = 0; k < ND; k++) nrm[k] = a.xn[s * ND + k];
       f[0] = a.f[s];
     }
   };
@@ -158,16 +159,25 @@ __global__ void __launch_bounds__(kWaveBlock) SCTL_AMD_MFMA_ATTR centered_mfma_f
 
   // ---- near sources: the reference-exact masked pair, in batches (as centered_kernel) ------------------------------------
   const R far_off = R(1.0e3) * (R(1) + sqrt_(rt2));
+  auto put_near = [&](int q, const R (&xq)[3], const R (&nq)[3], const R (&fq)[1]) {
+    R rec[4 * NEARW] = {};
+    pack_record<Ker, R, 0>(rec, xq, nq, fq);
+#pragma unroll
+    for (int g = 0; g < NEARW; g++) Rec4<R>::put(nearA + q * NEARW + g, rec[4 * g], rec[4 * g + 1], rec[4 * g + 2], rec[4 * g + 3]);
+  };
   int nn = 0;
   auto flush_near = [&]() {
     if (nn & 1) {
-      if (lane == 0) Rec4<R>::put(nearA + nn, c[0] + far_off, c[1], c[2], R(0));   // null source: zero density far away
+      if (lane == 0) {   // null source: zero density far away
+        const R xq[3] = {c[0] + far_off, c[1], c[2]}, nq[3] = {0, 0, 0}, fq[1] = {0};
+        put_near(nn, xq, nq, fq);
+      }
       __syncthreads();
     }
-    R xo[2][3];
+    R xo[NQ][3];
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
-      int64_t t = tbase + (2 * h + q) * 32 + m;
+    for (int q = 0; q < NQ; q++) {
+      int64_t t = tbase + (NQ * h + q) * 32 + m;
       if (t >= a.Nt) t = a.Nt - 1;
 #pragma unroll
       for (int k = 0; k < 3; k++) xo[q][k] = a.xt[t * 3 + k];
@@ -175,12 +185,20 @@ __global__ void __launch_bounds__(kWaveBlock) SCTL_AMD_MFMA_ATTR centered_mfma_f
     for (int s = 0; s < nn; s += 2) {
 #pragma unroll
       for (int u = 0; u < 2; u++) {
-        R w[4];
-        Rec4<R>::get(nearA + s + u, w);
+        R w[4 * NEARW];
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
+        for (int g = 0; g < NEARW; g++) {
+          R v[4];
+          Rec4<R>::get(nearA + (s + u) * NEARW + g, v);
+          w[4 * g] = v[0]; w[4 * g + 1] = v[1]; w[4 * g + 2] = v[2]; w[4 * g + 3] = v[3];
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
           const R d[3] = {xo[q][0] - w[0], xo[q][1] - w[1], xo[q][2] - w[2]};
-          Ker::pair<R, 0, true>(accn[q], d, w, a.ctx, K);
+          Ker::template pair<R, 0, true>(accn[q], d, w, a.ctx, K);
+#if !(defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_NO_NEAR_FENCE))
+          __builtin_amdgcn_sched_barrier(0);   // one pair after the other, never interleaved: see centered_kernel.hpp (flush_near)
+#endif
         }
       }
     }
@@ -204,60 +222,124 @@ __global__ void __launch_bounds__(kWaveBlock) SCTL_AMD_MFMA_ATTR centered_mfma_f
       __syncthreads();
     }
     if (is_far) {
-      const int q = carry + __popcll(bf & below);
-      __bf16 e[24];
-      source_row(p, ss, e);
-      farA[q * kRowWords] = word_of(e);
-      farA[q * kRowWords + 1] = word_of(e + 8);
-      farA[q * kRowWords + 2] = word_of(e + 16);
-      farF[q] = f[0];
+      u32x4* row = farA + (carry + __popcll(bf & below)) * RW;
+      row[0] = a_word(p[0]);
+      row[1] = a_word(p[1]);
+      row[2] = a_word(p[2]);
+      row[3] = a_tail(ss, true);
+      if constexpr (DL) {   // the numerator's row: -nf/2 against -2 x_t', -x_s'.nf against the ones (as CenteredDxU's far record)
+        const R nf[3] = {nrm[0] * f[0], nrm[1] * f[0], nrm[2] * f[0]};
+        row[4] = a_word(R(-0.5) * nf[0]);
+        row[5] = a_word(R(-0.5) * nf[1]);
+        row[6] = a_word(R(-0.5) * nf[2]);
+        row[7] = a_tail(-(p[0] * nf[0] + p[1] * nf[1] + p[2] * nf[2]), false);
+      } else {
+        farF[carry + __popcll(bf & below)] = f[0];
+      }
     } else if (is_near) {
-      Rec4<R>::put(nearA + nn + __popcll(bn & below), x[0], x[1], x[2], f[0]);
+      put_near(nn + __popcll(bn & below), x, nrm, f);
     }
     nn += nnear;
     return nfar;
   };
+  auto mfma = [](u32x4 A, u32x4 B, f32x16 C) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0); };
   // rows [0, nrows) of the far list, nrows a multiple of 32.  Per-call partial sums (two-level summation, as the VALU kernel)
   auto run_far = [&](int nrows) {
     f32x2 tacc[kColBlocks];
 #pragma unroll
     for (int cb = 0; cb < kColBlocks; cb++) tacc[cb] = f32x2{0, 0};
+    const f32x16 zero = {};
     for (int r0 = 0; r0 < nrows; r0 += kMfmaRows) {
-      const u32x4* row = farA + (r0 + m) * kRowWords + h;
-      const bf16x8 A0 = __builtin_bit_cast(bf16x8, row[0]), A1 = __builtin_bit_cast(bf16x8, row[2]);
-      f32x4 fr[4];   // densities of this lane's rows 8 k + 4 h + {0..3}
+      const u32x4* row = farA + (r0 + m) * RW + h;
+      const u32x4 A0 = row[0], A1 = row[2];
+      if constexpr (DL) {
+        const u32x4 G0 = row[4], G1 = row[6];
+        f32x16 r2 = mfma(A1, Bop[0][1], mfma(A0, Bop[0][0], zero)), rn = mfma(G1, Bop[0][1], mfma(G0, Bop[0][0], zero));
 #pragma unroll
-      for (int k = 0; k < 4; k++) fr[k] = farF4[(r0 >> 2) + 2 * k + h];
-      const f32x16 zero = {};
-      f32x16 r2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, __builtin_bit_cast(bf16x8, Bop[0][0]), zero, 0, 0, 0);
-      r2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, __builtin_bit_cast(bf16x8, Bop[0][1]), r2, 0, 0, 0);
+        for (int cb = 0; cb < kColBlocks; cb++) {
+          f32x16 r2n = r2, rnn = rn;
+          if (cb + 1 < kColBlocks) {   // the next block's contractions on the matrix cores while the VALU works on this one's
+            r2n = mfma(A1, Bop[cb + 1][1], mfma(A0, Bop[cb + 1][0], zero));
+            rnn = mfma(G1, Bop[cb + 1][1], mfma(G0, Bop[cb + 1][0], zero));
+          }
+          // in batches — 16 reciprocal square roots, their cubes, the accumulation — so that no instruction waits for the one before it
+          // (left to itself the compiler emitted rsq, rsq, mul, mul, fma as ONE dependent chain per register pair: 30 cycles per wave-pair)
+#ifndef SCTL_AMD_EXP_DL_BATCH
+#define SCTL_AMD_EXP_DL_BATCH 2
+#endif
+#if SCTL_AMD_EXP_DL_BATCH == 0   // (A/B builds) the plain loop
 #pragma unroll
-      for (int cb = 0; cb < kColBlocks; cb++) {
-        f32x16 nxt = r2;
-        if (cb + 1 < kColBlocks) {   // the next block's r2 on the matrix cores while the VALU works on this one's
-          nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, __builtin_bit_cast(bf16x8, Bop[cb + 1][0]), zero, 0, 0, 0);
-          nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, __builtin_bit_cast(bf16x8, Bop[cb + 1][1]), nxt, 0, 0, 0);
+          for (int v = 0; v < 16; v += 2) {
+            const f32x2 y = {__builtin_amdgcn_rsqf(r2[v]), __builtin_amdgcn_rsqf(r2[v + 1])};
+            tacc[cb] += f32x2{rn[v], rn[v + 1]} * (y * y * y);
+          }
+#else
+#pragma unroll
+          for (int v = 0; v < 16; v++) r2[v] = __builtin_amdgcn_rsqf(r2[v]);
+          __builtin_amdgcn_sched_barrier(0);
+#if SCTL_AMD_EXP_DL_BATCH == 1   // (A/B builds) cube per pair of values: 168 registers = three waves per SIMD, but y^2 -> y^3 back to back
+#pragma unroll
+          for (int v = 0; v < 16; v += 2) {
+            const f32x2 y = {r2[v], r2[v + 1]}, y3 = y * y * y;
+            r2[v] = y3[0]; r2[v + 1] = y3[1];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#else
+#pragma unroll
+          for (int v0 = 0; v0 < 16; v0 += 8) {   // (eight values at a time: a full set of squares costs 16 more registers)
+            f32x2 q[4];
+#pragma unroll
+            for (int v = 0; v < 8; v += 2) q[v >> 1] = f32x2{r2[v0 + v], r2[v0 + v + 1]} * f32x2{r2[v0 + v], r2[v0 + v + 1]};
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int v = 0; v < 8; v += 2) {
+              const f32x2 y3 = f32x2{r2[v0 + v], r2[v0 + v + 1]} * q[v >> 1];
+              r2[v0 + v] = y3[0]; r2[v0 + v + 1] = y3[1];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#endif
+          f32x2 t2 = {0, 0};   // a second chain: consecutive FMAs into one accumulator wait for each other
+#pragma unroll
+          for (int v = 0; v < 16; v += 4) {
+            tacc[cb] += f32x2{rn[v], rn[v + 1]} * f32x2{r2[v], r2[v + 1]};
+            t2 += f32x2{rn[v + 2], rn[v + 3]} * f32x2{r2[v + 2], r2[v + 3]};
+          }
+          tacc[cb] += t2;
+          __builtin_amdgcn_sched_barrier(0);
+#endif
+          r2 = r2n; rn = rnn;
         }
+        asm volatile("" ::"v"(A0), "v"(A1), "v"(G0), "v"(G1));   // operands stay untouched until the VALU work behind the last MFMA is done (see below)
+      } else {
+        f32x4 fr[4];   // densities of this lane's rows 8 k + 4 h + {0..3}
 #pragma unroll
-        for (int v = 0; v < 16; v += 2) {
-          const f32x2 y = {__builtin_amdgcn_rsqf(r2[v]), __builtin_amdgcn_rsqf(r2[v + 1])};
-          tacc[cb] += f32x2{fr[v >> 2][v & 3], fr[v >> 2][(v & 3) + 1]} * y;
+        for (int k = 0; k < 4; k++) fr[k] = farF4[(r0 >> 2) + 2 * k + h];
+        f32x16 r2 = mfma(A1, Bop[0][1], mfma(A0, Bop[0][0], zero));
+#pragma unroll
+        for (int cb = 0; cb < kColBlocks; cb++) {
+          f32x16 nxt = r2;
+          if (cb + 1 < kColBlocks) nxt = mfma(A1, Bop[cb + 1][1], mfma(A0, Bop[cb + 1][0], zero));
+#pragma unroll
+          for (int v = 0; v < 16; v += 2) {
+            const f32x2 y = {__builtin_amdgcn_rsqf(r2[v]), __builtin_amdgcn_rsqf(r2[v + 1])};
+            tacc[cb] += f32x2{fr[v >> 2][v & 3], fr[v >> 2][(v & 3) + 1]} * y;
+          }
+          r2 = nxt;
         }
-        r2 = nxt;
+        asm volatile("" ::"v"(A0), "v"(A1));
       }
     }
 #pragma unroll
     for (int cb = 0; cb < kColBlocks; cb++) acc[cb] += tacc[cb][0] + tacc[cb][1];
   };
-  // a null far row: r2 = 1 + |x_t'|^2 > 0 and zero density — contributes exactly 0
+  // a null far row: r2 = 1 + |x_t'|^2 > 0 and a zero density / numerator — contributes exactly 0
   auto put_null_far = [&](int q) {
-    __bf16 e[24];
-#pragma unroll
-    for (int k = 0; k < 24; k++) e[k] = (__bf16)((k == 18 || k >= 21) ? 1.0f : 0.0f);
-    farA[q * kRowWords] = word_of(e);
-    farA[q * kRowWords + 1] = word_of(e + 8);
-    farA[q * kRowWords + 2] = word_of(e + 16);
-    farF[q] = 0;
+    u32x4* row = farA + q * RW;
+    row[0] = row[1] = row[2] = u32x4{0, 0, 0, 0};
+    row[3] = a_tail(1.0f, true);
+    if constexpr (DL) row[4] = row[5] = row[6] = row[7] = u32x4{0, 0, 0, 0};
+    else farF[q] = 0;
   };
 
   int carry = 0;   // far rows left over from the previous tiles (wave-uniform, < 32)
@@ -268,10 +350,14 @@ __global__ void __launch_bounds__(kWaveBlock) SCTL_AMD_MFMA_ATTR centered_mfma_f
     run_far(nrows);
     carry = n - nrows;
     if (nrows > 0 && lane < carry) {   // the leftovers to the front (one wave: its LDS operations complete in program order)
-      const u32x4 w0 = farA[(nrows + lane) * kRowWords], w1 = farA[(nrows + lane) * kRowWords + 1], w2 = farA[(nrows + lane) * kRowWords + 2];
-      const float fv = farF[nrows + lane];
-      farA[lane * kRowWords] = w0; farA[lane * kRowWords + 1] = w1; farA[lane * kRowWords + 2] = w2;
-      farF[lane] = fv;
+      u32x4 w[RW - 1];
+#pragma unroll
+      for (int i = 0; i < RW - 1; i++) w[i] = farA[(nrows + lane) * RW + i];
+      float fv = 0;
+      if constexpr (!DL) fv = farF[nrows + lane];
+#pragma unroll
+      for (int i = 0; i < RW - 1; i++) farA[lane * RW + i] = w[i];
+      if constexpr (!DL) farF[lane] = fv;
     }
   }
   __syncthreads();
@@ -283,13 +369,21 @@ __global__ void __launch_bounds__(kWaveBlock) SCTL_AMD_MFMA_ATTR centered_mfma_f
   __syncthreads();
   flush_near();
 
+  // MEASURED on gfx950 (ROCm 7.2): a VALU write to a register that a just-issued v_mfma reads as its A or B operand can reach the register before the MFMA
+  // has read it, when the MFMA waits behind others in the matrix pipe (two waves per SIMD) — the compiler's hazard rules cover only the C operand.  In
+  // the last call of run_far the B operands are dead after their last MFMA and the register allocator handed them to the VALU work five instructions later:
+  // wrong sums for one column block in ~8 % of the waves, different from run to run.  So every MFMA operand is kept alive past the VALU batches that
+  // follow its last use: the A rows to the end of their row block (above), the B columns to here.
+#pragma unroll
+  for (int cb = 0; cb < kColBlocks; cb++) asm volatile("" ::"v"(Bop[cb][0]), "v"(Bop[cb][1]));
+
   // the two half-waves hold sums over different source rows of the same targets
 #pragma unroll
   for (int cb = 0; cb < kColBlocks; cb++) acc[cb] += __shfl_xor(acc[cb], 32);
 #pragma unroll
-  for (int q = 0; q < 2; q++) {
-    const int64_t t = tbase + (2 * h + q) * 32 + m;
-    const R sum = (h ? (q ? acc[3] : acc[2]) : (q ? acc[1] : acc[0])) + accn[q][0];
+  for (int q = 0; q < NQ; q++) {
+    const int64_t t = tbase + (NQ * h + q) * 32 + m;
+    const R sum = (h ? acc[NQ + q] : acc[q]) + accn[q][0];
     if (t < a.Nt) {
       if (gridDim.y == 1) a.v_trg[t] += sum * a.scale;
       else a.partial[(int64_t)split_idx * a.Nt + t] = sum;

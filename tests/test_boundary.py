@@ -98,6 +98,13 @@ def test_launch_planner():
         assert sctl_amd.plan("Laplace3D-FxU", 1, 1 << 20, 1 << 20)["path"] == "tile-centred"
         assert sctl_amd.plan("Laplace3D-DxU", 0, 1 << 20, 1 << 20)["path"] == "tile-centred"  # scalar Laplace kernels have a centred form
         assert sctl_amd.plan("Laplace3D-FxdU", 0, 1 << 20, 1 << 20)["path"] == "exact"        # the gradient needs x_t - x_s anyway
+        # which units run the far pairs (sctl_amd_eval_pipe): the bf16 matrix cores only for fp32 scalar Laplace at the seed's accuracy
+        if os.environ.get("SCTL_AMD_MFMA_F32") != "0":
+            for name in ("Laplace3D-FxU", "Laplace3D-DxU"):
+                assert sctl_amd.plan(name, 1, 1 << 20, 1 << 20)["pipe"].startswith("bf16 matrix cores")
+                assert sctl_amd.plan(name, 1, 1 << 20, 1 << 20, digits=9)["pipe"] == "vector pipe"
+                assert sctl_amd.plan(name, 0, 1 << 20, 1 << 20)["pipe"] == "vector pipe"
+        assert small["pipe"] == "vector pipe" and sctl_amd.plan("Stokes3D-FxU", 1, 1 << 20, 1 << 20)["pipe"] == "vector pipe"
         # a split's source data fits half an XCD's L2 (2 MB) and the splits come in eighths, one share per XCD (centered.hip)
         for name, real, logn in (("Laplace3D-FxU", 1, 23), ("Laplace3D-FxU", 1, 21), ("Laplace3D-DxU", 0, 20), ("Laplace3D-FxU", 0, 21)):
             p, i = sctl_amd.plan(name, real, 1 << logn, 1 << logn), sctl_amd.kernel_info(name)
@@ -174,3 +181,13 @@ def test_dropin_device_list_from_the_environment(oracle_mod):
     assert run(SCTL_AMD_DEVICES="1", SCTL_AMD_MIN_PAIRS_PER_DEVICE="12345")[:2] == ([1], 12345)
     assert run(SLURM_LOCALID="5")[0] == [5 % n_gpu if n_gpu else 0]                 # one rank per GPU under a launcher
     assert run(LOCAL_RANK="3", SCTL_AMD_DEVICES="0,1")[0] == [0, 1]                 # the explicit list wins
+
+
+def test_device_assembly_of_the_centred_kernels_is_free_of_the_two_measured_hazard_patterns():
+    """tools/check_mfma_operands.py on the assembly hipcc makes of sctl_amd/csrc/centered.hip with the library's own flags: no write to a v_mfma's A / B
+    registers within 24 instructions of its issue, and no packed instruction directly behind a transcendental one that overwrites its source — the two
+    patterns that went with wrong, run-to-run different sums on gfx950; the compiler emits both when left to itself."""
+    r = subprocess.run([os.sys.executable, os.path.join(ROOT, "tools", "check_mfma_operands.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count("v_mfma, 0 operand write(s)") == 4, r.stdout      # the four matrix-core kernels were found and are clean
+    assert "FAIL" not in r.stdout

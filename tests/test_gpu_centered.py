@@ -160,26 +160,60 @@ def test_one_process_multi_device_slabs_follow_the_morton_curve(O):
 
 
 @pytest.mark.parametrize("kind", ["uniform", "clustered", "surface", "identical_targets", "offset"])
-def test_centred_fp32_distance_on_the_matrix_cores_matches_the_packed_valu_kernel(O, kind):
-    """fp32 Laplace single layer: the kernel whose far-pair r^2 is a split-bf16 contraction on the matrix cores (centered_mfma_kernel.hpp, the
-    default) against the packed-VALU kernel (SCTL_AMD_MFMA_F32=0) and the fp64 oracle on the same fp32-rounded inputs, on the point clouds that
-    stress the far / near split; ragged sizes, so the last target tile, the last source tile and the carried leftovers are exercised."""
+@pytest.mark.parametrize("name", ["Laplace3D-FxU", "Laplace3D-DxU"])
+def test_centred_fp32_contractions_on_the_matrix_cores_match_the_packed_valu_kernel(O, name, kind):
+    """fp32 Laplace single and double layer: the kernel whose far-pair r^2 (and, for the double layer, (x_t - x_s).n f) is a split-bf16 contraction on
+    the matrix cores (centered_mfma_kernel.hpp, the default) against the packed-VALU kernel (SCTL_AMD_MFMA_F32=0) and the fp64 oracle on the same
+    fp32-rounded inputs, on the point clouds that stress the far / near split; ragged sizes, so the last target tile, the last source tile and the
+    carried leftovers are exercised."""
     import torch
     rng = np.random.default_rng(321)
     xt, xs = _clouds(kind, rng)
     xt, xs = np.ascontiguousarray(xt.ravel()).astype(np.float32), np.ascontiguousarray(xs.ravel()).astype(np.float32)
     f = (rng.random(NS) - 0.5).astype(np.float32)
-    assert sctl_amd.plan("Laplace3D-FxU", 1, NT, NS)["path"] == "tile-centred"
-    d = [torch.from_numpy(a).cuda() for a in (xt, xs, f)]
-    u = sctl_amd.eval_device("Laplace3D-FxU", d[0], d[1], None, d[2]).cpu().numpy()
+    xn = (rng.random(NS * 3) - 0.5).astype(np.float32) if name.endswith("DxU") else None
+    pl = sctl_amd.plan(name, 1, NT, NS)
+    assert pl["path"] == "tile-centred" and pl["pipe"].startswith("bf16 matrix cores"), pl
+    assert sctl_amd.plan(name, 1, NT, NS, digits=10)["pipe"] == "vector pipe" and sctl_amd.plan(name, 0, NT, NS)["pipe"] == "vector pipe"
+    d = [None if a is None else torch.from_numpy(a).cuda() for a in (xt, xs, xn, f)]
+    u = sctl_amd.eval_device(name, *d).cpu().numpy()
     assert np.all(np.isfinite(u))
     os.environ["SCTL_AMD_MFMA_F32"] = "0"
     try:
-        u_valu = sctl_amd.eval_device("Laplace3D-FxU", d[0], d[1], None, d[2]).cpu().numpy()
+        assert sctl_amd.plan(name, 1, NT, NS)["pipe"] == "vector pipe"
+        u_valu = sctl_amd.eval_device(name, *d).cpu().numpy()
     finally:
         del os.environ["SCTL_AMD_MFMA_F32"]
     sel = rng.choice(NT, 300, replace=False)
-    ref = O.eval("Laplace3D-FxU", xt.reshape(NT, 3)[sel].astype(np.float64).ravel().copy(), xs.astype(np.float64), None, f.astype(np.float64))
+    ref = O.eval(name, xt.reshape(NT, 3)[sel].astype(np.float64).ravel().copy(), xs.astype(np.float64), None if xn is None else xn.astype(np.float64),
+                 f.astype(np.float64))
     e_m, e_v = rel_l2(u[sel], ref), rel_l2(u_valu[sel], ref)
-    assert e_m <= 1e-4 and e_m <= 3 * e_v + 1e-6, (kind, e_m, e_v)
-    assert rel_l2(u, u_valu) <= 2e-5, (kind, rel_l2(u, u_valu))
+    # (the double layer's signed 1/r^2 terms nearly cancel on some of these clouds: both kernels then sit further from the fp64 result, together)
+    assert e_m <= (1e-4 if name.endswith("FxU") else 1e-3) and e_m <= 3 * e_v + 1e-6, (name, kind, e_m, e_v)
+    assert rel_l2(u, u_valu) <= (2e-5 if name.endswith("FxU") else 2e-4), (name, kind, rel_l2(u, u_valu))
+
+
+@pytest.mark.parametrize("kind", ["uniform", "clustered"])
+def test_centred_kernels_give_bit_identical_results_run_to_run(kind):
+    """Every sum runs in a fixed order, so repeated evaluations of one problem must agree to the last bit.  Round 3 found near-field sums of the fp32
+    double-layer kernels that did not (lanes 48-63 of waves that flush their list of near sources between tiles; centered_kernel.hpp: flush_near) — a
+    fault a tolerance test against the oracle sees only when it is large.  Both fp32 pipes, fp64, single and double layer; tools/near_determinism.py is
+    the long form (all kernels, a library built with the shortest near list)."""
+    import torch
+    rng = np.random.default_rng(99)
+    xt, xs = _clouds(kind, rng)
+    xn = rng.random(NS * 3) - 0.5
+    f = rng.random(NS) - 0.5
+    for dt in (np.float32, np.float64):
+        d = [torch.from_numpy(np.ascontiguousarray(a.ravel()).astype(dt)).cuda() for a in (xt, xs, xn, f)]
+        bits = torch.int32 if dt == np.float32 else torch.int64
+        for env in (("1", "0") if dt == np.float32 else ("1",)):
+            os.environ["SCTL_AMD_MFMA_F32"] = env
+            try:
+                for name in ("Laplace3D-FxU", "Laplace3D-DxU"):
+                    runs = [sctl_amd.eval_device(name, d[0], d[1], d[2] if name.endswith("DxU") else None, d[3]).clone() for _ in range(3)]
+                    assert bool(torch.isfinite(runs[0]).all())
+                    for r in runs[1:]:
+                        assert int((r.view(bits) != runs[0].view(bits)).sum()) == 0, (name, dt.__name__, env, kind)
+            finally:
+                del os.environ["SCTL_AMD_MFMA_F32"]
