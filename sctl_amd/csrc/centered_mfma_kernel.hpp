@@ -310,7 +310,7 @@ template <bool DL, int CB> __global__ void __launch_bounds__(kWaveBlock) SCTL_AM
 #endif
           r2 = r2n; rn = rnn;
         }
-        asm volatile("" ::"v"(A0), "v"(A1), "v"(G0), "v"(G1));   // operands stay untouched until the VALU work behind the last MFMA is done (see below)
+        asm volatile("" ::"v"(A0), "v"(A1), "v"(G0), "v"(G1));   // operands stay untouched until the VALU work behind the last MFMA is done (see the end of the kernel)
       } else {
         f32x4 fr[4];   // densities of this lane's rows 8 k + 4 h + {0..3}
 #pragma unroll
@@ -369,11 +369,11 @@ template <bool DL, int CB> __global__ void __launch_bounds__(kWaveBlock) SCTL_AM
   __syncthreads();
   flush_near();
 
-  // MEASURED on gfx950 (ROCm 7.2): a VALU write to a register that a just-issued v_mfma reads as its A or B operand can reach the register before the MFMA
-  // has read it, when the MFMA waits behind others in the matrix pipe (two waves per SIMD) — the compiler's hazard rules cover only the C operand.  In
-  // the last call of run_far the B operands are dead after their last MFMA and the register allocator handed them to the VALU work five instructions later:
-  // wrong sums for one column block in ~8 % of the waves, different from run to run.  So every MFMA operand is kept alive past the VALU batches that
-  // follow its last use: the A rows to the end of their row block (above), the B columns to here.
+  // A precaution, not a measured fix: in the last call of run_far the B operands are dead after their last MFMA, and the register allocator handed them
+  // to the VALU work five instructions behind it.  The compiler's hazard rules order a VALU write against an MFMA's C operand only; whether a write can
+  // reach an A / B register before an MFMA that waits in the matrix pipe has read it is not documented, and the fault first laid at this door turned out
+  // to be the near sums' (centered_kernel.hpp: flush_near).  Keeping every MFMA operand alive past the VALU batches that follow its last use costs
+  // nothing — the A rows to the end of their row block (above), the B columns to here — and tools/check_mfma_operands.py holds the assembly to it.
 #pragma unroll
   for (int cb = 0; cb < kColBlocks; cb++) asm volatile("" ::"v"(Bop[cb][0]), "v"(Bop[cb][1]));
 

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Static checks of the device assembly (no GPU needed) for two instruction patterns that went with wrong, run-to-run different results on gfx950
-(ROCm 7.2) and that the compiler's hazard rules do not exclude (sctl_amd/csrc/centered_mfma_kernel.hpp, centered_kernel.hpp):
- (1) a VALU / LDS / memory-load write to a register that a recently issued v_mfma reads as its A or B operand (the write can land before the MFMA has
-     read it when the MFMA waits behind others in the matrix pipe): for every v_mfma of the matrix-core kernels the next WINDOW vector / LDS / memory
-     instructions along both arms of every branch must not write the MFMA's A / B registers (its own destination included);
+"""Static checks of the device assembly (no GPU needed) for two instruction patterns the compiler's hazard rules do not exclude and this repository
+keeps out of its matrix-core kernels (sctl_amd/csrc/centered_mfma_kernel.hpp, centered_kernel.hpp):
+ (1) a VALU / LDS / memory-load write to a register that a recently issued v_mfma reads as its A or B operand (a precaution: whether such a write can
+     land before an MFMA that waits in the matrix pipe has read the register is not documented): for every v_mfma of the matrix-core kernels the next
+     WINDOW vector / LDS / memory instructions along both arms of every branch must not write the MFMA's A / B registers (its own destination included);
  (2) a PACKED vector instruction (v_pk_*) directly behind a transcendental one (v_rsq / v_rcp / v_sqrt / v_exp / v_log / v_sin / v_cos) that overwrites
      the transcendental's source register — in every kernel of the file: the pair stood where the matrix-core double-layer kernel's near sums
      went wrong, and removing it (a scheduling fence) removed the fault; a microbenchmark of the bare pair does not reproduce it, so this is a
