@@ -456,7 +456,7 @@ def main():
             # has the same dense peak as the fp64 (fp32) MFMA path, 78.6 (157.3) TFLOP/s, and shares its issue slots
             # (fp32 Laplace SL takes the far pairs' r^2 from the bf16 matrix cores, sctl_amd_eval_pipe; the fraction stays against the fp32 peak)
             "roofline": {"bound": "mfma", "pipe": ("fp64 VALU" if dtype == "f64" else "fp32 VALU") if plan["pipe"] == "vector pipe" else
-                                                  "bf16 MFMA (r^2 as a split-bf16 contraction, K = 24) + fp32 VALU (v_rsq_f32, accumulate)",
+                                                  "bf16 MFMA (r^2 as a split-bf16 contraction, K = 30) + fp32 VALU (v_rsq_f32, accumulate)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": read_traffic(args.workload) if world == 1 else None,
                          "flops_per_pair": fpp, "kernel_ms": k_ms,
