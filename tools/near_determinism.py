@@ -54,5 +54,22 @@ for name in sctl_amd.KERNEL_NAMES:
         nb, _ = differing(lambda: sctl_amd.eval_device(name, a[0], a[1], a[2] if info["nd"] else None, a[3], ctx=ctx))
         bad_total += nb
         print("%-22s %-18s %s 2^14 x 2^14 (exact path)   values differing between %d runs: %d" % (lib, name, "f32" if dt == torch.float32 else "f64", REPS, nb), flush=True)
+# (3) the batched list kernel (one launch, a wave per work item: sums in list order)
+from sctl_amd.lists import grid_neighbour_lists, points_in_boxes
+rng = np.random.default_rng(5)
+cnt = rng.integers(1, 200, 12 ** 3)
+x = points_in_boxes(12, cnt, rng)
+lists = grid_neighbour_lists(12, cnt, cnt)
+for name in ("Laplace3D-FxU", "Stokes3D-FxU", "Laplace3D-DxU"):
+    info = sctl_amd.kernel_info(name)
+    for dt in (np.float32, np.float64):
+        fl = (rng.random(int(cnt.sum()) * info["k0"]) - 0.5).astype(dt)
+        nl = (rng.random(int(cnt.sum()) * info["nd"]) - 0.5).astype(dt) if info["nd"] else None
+        runs = [sctl_amd.eval_lists_host(name, *lists, x.astype(dt), x.astype(dt), nl, fl) for _ in range(REPS)]
+        assert np.all(np.isfinite(runs[0]))
+        bits = np.int32 if dt == np.float32 else np.int64
+        nb = sum(int((runs[i].view(bits) != runs[0].view(bits)).sum()) for i in range(1, REPS))
+        bad_total += nb
+        print("%-22s %-18s %s %d lists, %d points (list kernel)   values differing between %d runs: %d" % (lib, name, "f32" if dt == np.float32 else "f64", lists[0].size, int(cnt.sum()), REPS, nb), flush=True)
 print("TOTAL differing:", bad_total)
 sys.exit(1 if bad_total else 0)

@@ -15,6 +15,7 @@ import sys
 
 tag, workload = sys.argv[1], sys.argv[2]
 P = "gpurun_out/prof_" + tag
+q = lambda name: '"%s"' % name if "," in name else name      # kernel names with template arguments carry commas
 os.makedirs("profiles", exist_ok=True)
 
 
@@ -36,7 +37,7 @@ with open("profiles/%s_kernel_stats.csv" % tag, "w") as fh:
     fh.write("# rocprofv3 --kernel-trace --stats of: python bench.py --steps 3 --warmup 1 --no-cpu-baseline (workload %s)\n" % workload)
     fh.write("kernel,calls,total_ns,average_ns,percentage\n")
     for r in rows:
-        fh.write("%s,%s,%s,%s,%s\n" % (short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]))
+        fh.write("%s,%s,%s,%s,%s\n" % (q(short(r["Name"])), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]))
 want = sys.argv[3] if len(sys.argv) > 3 else ""
 dominant = max((r for r in rows if want in r["Name"]), key=lambda r: float(r["TotalDurationNs"]))
 summ = collections.defaultdict(dict)
@@ -59,7 +60,7 @@ with open("profiles/%s_pmc_summary.csv" % tag, "w") as fh:
     fh.write("kernel,launch_geometry,counter,launches,mean_per_launch\n")
     for k, d in summ.items():
         for c, (n, m) in sorted(d.items()):
-            fh.write("%s,%s,%s,%d,%.6g\n" % (k, meta[k], c, n, m))
+            fh.write("%s,%s,%s,%d,%.6g\n" % (q(k), meta[k], c, n, m))
 dk = short(dominant["Name"])
 fetch_kb, write_kb = summ[dk]["FETCH_SIZE"][1], summ[dk]["WRITE_SIZE"][1]
 path = "profiles/hbm_traffic.json"
