@@ -325,6 +325,9 @@ template <bool DL, int CB> __global__ void __launch_bounds__(kWaveBlock) SCTL_AM
             const f32x2 y = {__builtin_amdgcn_rsqf(r2[v]), __builtin_amdgcn_rsqf(r2[v + 1])};
             tacc[cb] += f32x2{fr[v >> 2][v & 3], fr[v >> 2][(v & 3) + 1]} * y;
           }
+#if defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_SL_STEP_FENCE)   // A/B builds: one column block's MFMAs ahead, no more (two result sets instead of four)
+          __builtin_amdgcn_sched_barrier(0);
+#endif
           r2 = nxt;
         }
         asm volatile("" ::"v"(A0), "v"(A1));
