@@ -325,16 +325,22 @@ __global__ void __launch_bounds__(kWaveBlock) SCTL_AMD_CENTERED_ATTR centered_ke
         for (int j = 0; j < T; j++) {
           const R d[3] = {xo[j][0] - q[0], xo[j][1] - q[1], xo[j][2] - q[2]};
           Ker::template pair<R, MODE, true>(acc[j], d, q, a.ctx, K);
-          // One pair after the other, never interleaved.  MEASURED on gfx950 (round 3, ROCm 7.2): the matrix-core double-layer kernel with 128 targets per
-          // wave (centered_mfma_kernel.hpp) gave near sums that differed from RUN TO RUN — lanes 48-63, the first of the lane's targets, only in waves that
-          // flush their near list between tiles; 7 000 of 2^18 targets, errors up to O(1) — while its far sums and, in builds that kept only one of the two,
-          // each sum alone were bit-stable.  With the two targets' pairs interleaved hipcc had emitted `v_rsq_f32 v34, v36` directly followed by
-          // `v_pk_mul_f32 v[36:37], ...`: the next instruction overwrites the transcendental's source, and the wrong values are those that come from that
-          // v_rsq.  With this fence the pattern is gone and every result is bit-identical run to run (tools/near_determinism.py: with / without the fence,
-          // near list of 64 / 128, profiles/r03_near_determinism.txt).  NOT isolated: the bare instruction pair in a microbenchmark
-          // (tools/ubench/trans_war.hip) and the packed-VALU double-layer kernel here, which carried the same pair, do not show it — the pair is necessary in
-          // what was seen, not sufficient.  tools/check_mfma_operands.py looks for it in the assembly of every build (tests/test_boundary.py), and
-          // tests/test_gpu_centered.py asks for bit-identical repeats.
+          // One pair after the other, never interleaved.  MEASURED on gfx950 (round 3, ROCm 7.2): without this fence ONE instantiation, the matrix-core
+          // double-layer kernel with 128 targets per wave (centered_mfma_kernel.hpp), gave near sums that differed from RUN TO RUN — lanes 48-63, the first of
+          // the lane's targets, only in waves that flush their near list between tiles; ~500 of 2^17 targets per run, errors up to O(1).  What is known
+          // (tools/kernel_repeat.sh, profiles/r03_kernel_repeat.txt: code objects of that build, its assembly patched, 24 launches each):
+          //   - it is a TIMING fault of the compiled code, not a data race of the source: `s_nop 3` behind every instruction of the kernel cures it (0 of 24
+          //     runs off), the same nops only inside or only outside the near-flush region do not; LDS or vector registers filled with NaN patterns between
+          //     launches change nothing and no NaN comes out, so nothing unwritten is read;
+          //   - it shows only when ANOTHER kernel ran since the last launch (any kernel; 24 of 24 runs off) and never in launches back to back — cold
+          //     instruction caches on a path that runs once per few hundred tiles;
+          //   - hipcc had interleaved the two targets' pairs into `v_rsq_f32 v34, v36 ; v_pk_mul_f32 v[36:37], ...` (the next instruction overwrites the
+          //     transcendental's source), the first suspect: one s_nop between the two does NOT cure it, and a microbenchmark of the pair is clean
+          //     (tools/ubench/trans_war.hip) — refuted;
+          //   - with the fence — other instruction order, same arithmetic — all four matrix-core kernels and the packed-VALU ones are bit-stable in that
+          //     detector and in tools/near_determinism.py (shortest near list, both targets-per-wave forms).
+          // The hardware mechanism is NOT identified.  What guards the shipped kernels is therefore a test, not a rule: tests/test_gpu_centered.py asks for
+          // bit-identical repeats with other kernels in between, for both layers, both fp32 pipes and fp64.
 #if !(defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_NO_NEAR_FENCE))   // (the A/B build of tools/near_determinism.py)
           __builtin_amdgcn_sched_barrier(0);
 #endif

@@ -195,10 +195,11 @@ def test_centred_fp32_contractions_on_the_matrix_cores_match_the_packed_valu_ker
 
 @pytest.mark.parametrize("kind", ["uniform", "clustered"])
 def test_centred_kernels_give_bit_identical_results_run_to_run(kind):
-    """Every sum runs in a fixed order, so repeated evaluations of one problem must agree to the last bit.  Round 3 found near-field sums of the fp32
-    double-layer kernels that did not (lanes 48-63 of waves that flush their list of near sources between tiles; centered_kernel.hpp: flush_near) — a
-    fault a tolerance test against the oracle sees only when it is large.  Both fp32 pipes, fp64, single and double layer; tools/near_determinism.py is
-    the long form (all kernels, a library built with the shortest near list)."""
+    """Every sum runs in a fixed order, so repeated evaluations of one problem must agree to the last bit.  Round 3 found near-field sums of one
+    instantiation of the fp32 double-layer kernels that did not (a timing fault of the compiled code in the path that flushes the list of near sources
+    between tiles; centered_kernel.hpp: flush_near) — a fault a tolerance test against the oracle sees only when it is large, and one that
+    shows only when OTHER kernels run between the launches: here the copy of every result and the fills of the next output do that.  Both fp32 pipes,
+    fp64, single and double layer; tools/near_determinism.py and tools/kernel_repeat.sh are the long forms."""
     import torch
     rng = np.random.default_rng(99)
     xt, xs = _clouds(kind, rng)

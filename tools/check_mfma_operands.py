@@ -1,13 +1,12 @@
 #!/usr/bin/env python3
-"""Static checks of the device assembly (no GPU needed) for two instruction patterns the compiler's hazard rules do not exclude and this repository
-keeps out of its matrix-core kernels (sctl_amd/csrc/centered_mfma_kernel.hpp, centered_kernel.hpp):
- (1) a VALU / LDS / memory-load write to a register that a recently issued v_mfma reads as its A or B operand (a precaution: whether such a write can
-     land before an MFMA that waits in the matrix pipe has read the register is not documented): for every v_mfma of the matrix-core kernels the next
-     WINDOW vector / LDS / memory instructions along both arms of every branch must not write the MFMA's A / B registers (its own destination included);
- (2) a PACKED vector instruction (v_pk_*) directly behind a transcendental one (v_rsq / v_rcp / v_sqrt / v_exp / v_log / v_sin / v_cos) that overwrites
-     the transcendental's source register — in every kernel of the file: the pair stood where the matrix-core double-layer kernel's near sums
-     went wrong, and removing it (a scheduling fence) removed the fault; a microbenchmark of the bare pair does not reproduce it, so this is a
-     necessary-in-what-was-seen rule, kept because it costs nothing.  Other followers that overwrite the source are counted and listed, not failed.
+"""Static check of the device assembly (no GPU needed) for an instruction pattern the compiler's hazard rules do not exclude and this repository keeps
+out of its matrix-core kernels (sctl_amd/csrc/centered_mfma_kernel.hpp): a VALU / LDS / memory-load write to a register that a recently
+issued v_mfma reads as its A or B operand.  A precaution — whether such a write can land before an MFMA that waits in the matrix pipe has read the register
+is not documented —: for every v_mfma of the matrix-core kernels the next WINDOW vector / LDS / memory instructions along both arms of every branch must not
+write the MFMA's A / B registers (its own destination included).
+It also LISTS (does not fail) vector instructions directly behind a transcendental one that overwrite the transcendental's source register: the pair
+`v_rsq_f32 vA, vB ; v_pk_mul_f32 v[B:B+1]` was the first suspect for the run-to-run different near sums of round 3 and was cleared by experiment
+(tools/kernel_repeat.sh: one s_nop between the two does not remove the fault) — kept as information for whoever meets that fault again.
     python tools/check_mfma_operands.py [asm file]      exit code 1 on a finding; without a file it compiles sctl_amd/csrc/centered.hip"""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -126,12 +125,11 @@ def main():
     for name, body in kernels(src, "sctl_amd"):
         packed, other = check_trans(body)
         if packed or other:
-            print("%s: transcendental source overwritten by the next instruction: %d packed (fails), %d other (listed)" % (name, len(packed), len(other)))
+            print("%s: transcendental source overwritten by the next instruction (listed, not a failure): %d packed, %d other" % (name, len(packed), len(other)))
             for i, a, b in packed:
-                print("   FAIL line %d  %s ; %s" % (i, a, b))
+                print("        line %d  %s ; %s   [packed]" % (i, a, b))
             for i, a, b in other[:4]:
                 print("        line %d  %s ; %s" % (i, a, b))
-        bad += len(packed)
     return 1 if bad else 0
 
 

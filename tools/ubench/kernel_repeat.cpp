@@ -1,0 +1,125 @@
+// Bit-for-bit repeatability of ONE kernel taken from a code object, under the condition that exposes timing faults: another kernel runs between any two
+// launches (POISON=1; or fills every CU's LDS / most vector registers with a pattern: POISON=0x7fc00000, POISON_VGPR=1), so that every launch starts with cold
+// instruction caches and foreign machine state.  Written to pin down the run-to-run different near sums of centered_mfma_f32_kernel<true, 4> built WITHOUT the
+// near fence; tools/kernel_repeat.sh builds the code objects — the shipped kernels, the no-fence build, and that build's assembly with
+// s_nop instructions patched in — and runs them.  KERNEL = the template arguments of centered_mfma_f32_kernel<DL, CB> as mangled (default ILb1ELi4E).
+//   hipcc -O2 --offload-arch=gfx950 tools/ubench/kernel_repeat.cpp -o tools/ubench/kernel_repeat && POISON=1 tools/ubench/kernel_repeat a.co [b.co ...]
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+struct Args {   // EvalArgs<float> of include/sctl_amd/device/eval_kernel.hpp
+  int64_t Nt, Ns;
+  const float *xt, *xs, *xn, *f;
+  float *v_trg, *partial;
+  int64_t chunk;
+  float scale;
+  double ctx[4];
+};
+// fills every CU's LDS with a bit pattern (a NaN by default): a kernel that reads LDS it has not written then shows it
+__global__ void __launch_bounds__(256) poison_lds(unsigned pattern, unsigned* sink) {
+  __shared__ unsigned buf[160 * 1024 / 4 - 64];
+  if (pattern != 1u)   // pattern 1: the kernel runs and leaves LDS alone
+    for (int i = threadIdx.x; i < (int)(sizeof(buf) / 4); i += 256) buf[i] = pattern;
+  __syncthreads();
+  if (buf[(threadIdx.x * 97) % (sizeof(buf) / 4)] == 12345u) sink[0] = 1;   // keeps the stores alive
+}
+// leaves a bit pattern in (nearly) every vector register of every SIMD: a kernel that reads a register it has not written then shows it
+__global__ void __launch_bounds__(64) poison_vgprs(const unsigned* src, unsigned* sink) {
+  unsigned r[240];
+#pragma unroll
+  for (int i = 0; i < 240; i++) r[i] = src[i];                     // all NaN patterns
+  asm volatile("" ::: "memory");
+  unsigned acc = 0;
+#pragma unroll
+  for (int i = 0; i < 240; i++) { asm volatile("" : "+v"(r[i])); acc ^= r[i]; }
+  if (acc == 12345u) sink[threadIdx.x] = acc;
+}
+static uint64_t spread(uint64_t v) {
+  v &= 0x1fffff; v = (v | v << 32) & 0x1f00000000ffffull; v = (v | v << 16) & 0x1f0000ff0000ffull; v = (v | v << 8) & 0x100f00f00f00f00full;
+  v = (v | v << 4) & 0x10c30c30c30c30c3ull; v = (v | v << 2) & 0x1249249249249249ull;
+  return v;
+}
+constexpr int REPS = 24;
+int main(int argc, char** argv) {
+  if (argc < 2) { fprintf(stderr, "usage: %s a.co [b.co ...]\n", argv[0]); return 2; }
+  const int64_t Nt = 1 << 17, Ns = 1 << 16;
+  srand48(1);
+  std::vector<float> xt(Nt * 3), xs(Ns * 3), xn(Ns * 3), f(Ns);
+  {
+    std::vector<std::pair<uint64_t, int64_t>> key(Nt);
+    std::vector<float> raw(Nt * 3);
+    for (auto& v : raw) v = (float)drand48();
+    for (int64_t i = 0; i < Nt; i++) {
+      uint64_t k = 0;
+      for (int d = 0; d < 3; d++) k |= spread((uint64_t)(raw[i * 3 + d] * 2097151.0f)) << d;
+      key[i] = {k, i};
+    }
+    std::sort(key.begin(), key.end());
+    for (int64_t i = 0; i < Nt; i++) for (int d = 0; d < 3; d++) xt[i * 3 + d] = raw[key[i].second * 3 + d];
+  }
+  for (auto& v : xs) v = (float)drand48();
+  for (auto& v : xn) v = (float)drand48() - 0.5f;
+  for (auto& v : f) v = (float)drand48() - 0.5f;
+  float *dxt, *dxs, *dxn, *df, *dv;
+  CHECK(hipMalloc(&dxt, xt.size() * 4)); CHECK(hipMalloc(&dxs, xs.size() * 4)); CHECK(hipMalloc(&dxn, xn.size() * 4)); CHECK(hipMalloc(&df, f.size() * 4));
+  CHECK(hipMalloc(&dv, (size_t)REPS * Nt * 4));
+  CHECK(hipMemcpy(dxt, xt.data(), xt.size() * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(dxs, xs.data(), xs.size() * 4, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(dxn, xn.data(), xn.size() * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(df, f.data(), f.size() * 4, hipMemcpyHostToDevice));
+  unsigned *dv_sink, *dnan; CHECK(hipMalloc(&dv_sink, 1024)); CHECK(hipMalloc(&dnan, 1024));
+  { std::vector<unsigned> nanv(256, 0x7fc00000u); CHECK(hipMemcpy(dnan, nanv.data(), 1024, hipMemcpyHostToDevice)); }
+  Args a{};
+  a.Nt = Nt; a.Ns = Ns; a.xt = dxt; a.xs = dxs; a.xn = dxn; a.f = df; a.v_trg = dv; a.partial = nullptr; a.chunk = Ns; a.scale = 0.0795774715f; a.ctx[0] = 4.0;
+  std::vector<std::vector<uint32_t>> first;
+  for (int m = 1; m < argc; m++) {
+    hipModule_t mod; hipFunction_t fn;
+    CHECK(hipModuleLoad(&mod, argv[m]));
+    // KERNEL: template arguments of centered_mfma_f32_kernel<DL, CB> as mangled, e.g. ILb1ELi4E (double layer, 128 targets per wave; the default)
+    const char* targs = getenv("KERNEL") ? getenv("KERNEL") : "ILb1ELi4E";
+    const int per_wave = strstr(targs, "Li8E") ? 256 : 128;
+    char sym[256];
+    snprintf(sym, sizeof(sym), "_ZN8sctl_amd24centered_mfma_f32_kernel%sEEvNS_8EvalArgsIfEE", targs);
+    CHECK(hipModuleGetFunction(&fn, mod, sym));
+    std::vector<std::vector<uint32_t>> runs;
+    CHECK(hipMemset(dv, 0, (size_t)REPS * Nt * 4));
+    // all runs queued back to back, each into its own zeroed output (a busy GPU: the fault is rare when every launch starts on an idle chip)
+    for (int rep = 0; rep < REPS; rep++) {
+      if (getenv("POISON")) hipLaunchKernelGGL(poison_lds, dim3(2048), dim3(256), 0, 0, (unsigned)strtoul(getenv("POISON"), nullptr, 0) + (getenv("POISON_VARY") ? (unsigned)rep * 0x1111u : 0u), (unsigned*)dv_sink);
+      if (getenv("POISON_VGPR")) hipLaunchKernelGGL(poison_vgprs, dim3(16384), dim3(64), 0, 0, (const unsigned*)dnan, (unsigned*)dv_sink);
+      Args b = a;
+      b.v_trg = dv + (int64_t)rep * Nt;
+      size_t sz = sizeof(b);
+      void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &b, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+      CHECK(hipModuleLaunchKernel(fn, (unsigned)(Nt / per_wave), 1, 1, 64, 1, 1, 0, 0, nullptr, extra));
+    }
+    CHECK(hipDeviceSynchronize());
+    for (int rep = 0; rep < REPS; rep++) {
+      std::vector<uint32_t> h(Nt);
+      CHECK(hipMemcpy(h.data(), dv + (int64_t)rep * Nt, Nt * 4, hipMemcpyDeviceToHost));
+      runs.push_back(h);
+    }
+    // the value most runs agree on, target by target, is taken as this code object's result; a run "differs" when any of its values is another one
+    long bad_runs = 0, bad_values = 0, nonfinite = 0;
+    std::vector<uint32_t> ref(Nt);
+    for (int64_t i = 0; i < Nt; i++) {
+      int best = 0, bestc = 0;
+      for (int r = 0; r < REPS && bestc <= REPS / 2; r++) { int c = 0; for (int q = 0; q < REPS; q++) c += runs[q][i] == runs[r][i]; if (c > bestc) { bestc = c; best = r; } }
+      ref[i] = runs[best][i];
+      nonfinite += ((ref[i] >> 23) & 0xff) == 0xff;
+    }
+    for (int r = 0; r < REPS; r++) { long n = 0; for (int64_t i = 0; i < Nt; i++) n += runs[r][i] != ref[i]; bad_values += n; bad_runs += n > 0; }
+    long vs_first = -1;
+    if (!first.empty()) { vs_first = 0; for (int64_t i = 0; i < Nt; i++) vs_first += ref[i] != first[0][i]; }
+    printf("%-28s %-10s %d runs of 2^17 x 2^16: runs with a value off the majority result %ld, such values %ld, non-finite %ld%s\n", argv[m], targs, REPS, bad_runs, bad_values, nonfinite,
+           vs_first < 0 ? "" : (vs_first ? "   (majority result differs from the first code object's)" : "   (majority result identical to the first code object's)"));
+    runs.assign(1, ref);
+    if (first.empty()) first = runs;
+    CHECK(hipModuleUnload(mod));
+  }
+  return 0;
+}
