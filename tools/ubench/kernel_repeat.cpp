@@ -95,7 +95,7 @@ int main(int argc, char** argv) {
       b.v_trg = dv + (int64_t)rep * Nt;
       size_t sz = sizeof(b);
       void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &b, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-      CHECK(hipModuleLaunchKernel(fn, (unsigned)(Nt / per_wave), 1, 1, 64, 1, 1, 0, 0, nullptr, extra));
+      CHECK(hipModuleLaunchKernel(fn, (unsigned)(Nt / per_wave), 1, 1, 64, 1, 1, getenv("DYN_LDS") ? (unsigned)atoi(getenv("DYN_LDS")) : 0u, 0, nullptr, extra));   // DYN_LDS: extra LDS per workgroup = fewer waves per CU
     }
     CHECK(hipDeviceSynchronize());
     for (int rep = 0; rep < REPS; rep++) {

@@ -116,8 +116,62 @@ template <int GAP, bool PK> void run2(int waves_per_simd) {
   CHECK(hipFree(in)); CHECK(hipFree(bad));
 }
 
+// A third shape: the hypothesis that explains the fault of DESIGN.md §4.2a.  Two roles share every SIMD (512-thread workgroups: waves w and w + 4):
+//   role B (waves 4..7): bursts of BURST back-to-back independent v_rsq_f32 — what the batched far loop of the matrix-core double-layer kernel issues;
+//   role A (waves 0..3): y = rsq(x) DIRECTLY followed by an instruction that overwrites x (PK: v_pk_mul_f32 on the pair, else v_mov_b32), then idle.
+// If a transcendental reads its source when it reaches the head of the SIMD's transcendental queue rather than at issue, role A's rsq — waiting behind
+// role B's burst — sees the overwritten register.
+template <int BURST, bool PK, int GAPNOPS> __global__ void __launch_bounds__(512) kern3(const float* in, unsigned* bad, int iters) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float x0 = in[blockIdx.x * blockDim.x + threadIdx.x];
+  unsigned nbad = 0;
+  float other = 3.0f + lane;
+  if (wave >= 4) {   // role B
+    float a0 = x0, a1 = x0 + 1, a2 = x0 + 2, a3 = x0 + 3, r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+    for (int it = 0; it < iters * 2; it++) {
+#pragma unroll
+      for (int b = 0; b < BURST; b += 4)
+        asm volatile("v_rsq_f32 %0, %4\n\tv_rsq_f32 %1, %5\n\tv_rsq_f32 %2, %6\n\tv_rsq_f32 %3, %7" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+      a0 += r0 * 1e-30f;
+    }
+    if (a0 == 12345.0f) bad[0] = 1;
+    return;
+  }
+  for (int it = 0; it < iters; it++) {
+    const float xin = x0 + it;
+    const float expect = __builtin_amdgcn_rsqf(xin);
+    const f2 o2 = {other, other};
+    float y;
+#define HEAD3 "v_mov_b32 v40, %1\n\tv_mov_b32 v41, %1\n\ts_nop 3\n\tv_rsq_f32 %0, v40\n\t"
+#define OPS3 : "=&v"(y) : "v"(xin), "v"(other), "v"(o2) : "v40", "v41"
+    if (PK && GAPNOPS == 0) asm volatile(HEAD3 "v_pk_mul_f32 v[40:41], %3, %3\n\ts_nop 7" OPS3);
+    if (PK && GAPNOPS == 1) asm volatile(HEAD3 "s_nop 0\n\tv_pk_mul_f32 v[40:41], %3, %3\n\ts_nop 7" OPS3);
+    if (PK && GAPNOPS == 16) asm volatile(HEAD3 "s_nop 15\n\tv_pk_mul_f32 v[40:41], %3, %3\n\ts_nop 7" OPS3);
+    if (!PK && GAPNOPS == 0) asm volatile(HEAD3 "v_mov_b32 v40, %2\n\ts_nop 7" OPS3);
+    if (y != expect) nbad++;
+    other += y * 1e-30f;
+  }
+  atomicAdd(&bad[lane >> 4], nbad);
+}
+template <int BURST, bool PK, int GAPNOPS> void run3() {
+  const int nblk = 256, threads = 512, iters = 20000;
+  std::vector<float> h((size_t)nblk * threads);
+  for (size_t i = 0; i < h.size(); i++) h[i] = 1.0f + (float)(i % 977) * 0.37f;
+  float* in; unsigned* bad;
+  CHECK(hipMalloc(&in, h.size() * sizeof(float))); CHECK(hipMalloc(&bad, 4 * sizeof(unsigned)));
+  CHECK(hipMemcpy(in, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice)); CHECK(hipMemset(bad, 0, 4 * sizeof(unsigned)));
+  hipLaunchKernelGGL((kern3<BURST, PK, GAPNOPS>), dim3(nblk), dim3(threads), 0, 0, in, bad, iters);
+  CHECK(hipDeviceSynchronize());
+  unsigned hb[4]; CHECK(hipMemcpy(hb, bad, sizeof(hb), hipMemcpyDeviceToHost));
+  const double total = (double)nblk * 256 * iters / 4;
+  printf("beside a wave issuing bursts of %2d v_rsq_f32:  v_rsq_f32 y, x ; %s%-26s wrong, lanes 0-15 / 16-31 / 32-47 / 48-63: %.3g / %.3g / %.3g / %.3g\n", BURST,
+         GAPNOPS == 0 ? "" : (GAPNOPS == 1 ? "s_nop 0 ; " : "s_nop 15 ; "), PK ? "v_pk_mul_f32 {x, x'}, o, o" : "v_mov_b32 x, other", hb[0] / total, hb[1] / total, hb[2] / total, hb[3] / total);
+  CHECK(hipFree(in)); CHECK(hipFree(bad));
+}
+
 int main() {
   CHECK(hipSetDevice(0));
+  run3<4, true, 0>(); run3<16, true, 0>(); run3<32, true, 0>(); run3<32, false, 0>(); run3<32, true, 1>(); run3<32, true, 16>();
   for (int w = 1; w <= 4; w *= 2) {
     run<0, 0>("v_rsq_f32 y, x ; v_mov_b32 x, other", w);
     run<1, 0>("v_rsq_f32 y, x ; v_pk_mul_f32 {x, x'}, o, o", w);
