@@ -403,3 +403,36 @@ def test_init_and_finalize_are_optional_and_repeatable(O):
             assert rel_l2(sctl_amd.eval_host("Stokes3D-FxU", xt, xs, None, f, devices=devices), ref) < 1e-12
             sctl_amd.finalize()
     assert sctl_amd.init() == torch.cuda.device_count()
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32], ids=["f64", "f32"])
+def test_every_kernel_gives_bit_identical_results_run_to_run(dt):
+    """No sum is accumulated with atomics and every reduction runs in a fixed order, so repeated evaluations must agree to the last bit — through the exact
+    all-pairs kernels (with source splits and their reduction), KernelMatrix and the batched list kernel, with other kernels (copies, fills) between the
+    launches.  The counterpart for the tile-centred kernels, where round 3 found a timing fault of compiled code, is in test_gpu_centered.py."""
+    import torch
+    from sctl_amd.lists import grid_neighbour_lists, points_in_boxes
+    rng = np.random.default_rng(17)
+    Nt, Ns = 20000, 33000
+    bits = np.int32 if dt == np.float32 else np.int64
+    cnt = rng.integers(1, 90, 6 ** 3)
+    xl = points_in_boxes(6, cnt, rng).astype(dt)
+    lists = grid_neighbour_lists(6, cnt, cnt)
+    for name in sctl_amd.KERNEL_NAMES:
+        info = sctl_amd.kernel_info(name)
+        ctx = ctx_for(name)
+        xt, xs = rng.random(Nt * 3).astype(dt), rng.random(Ns * 3).astype(dt)
+        xn = (rng.random(Ns * info["nd"]) - 0.5).astype(dt) if info["nd"] else None
+        f = (rng.random(Ns * info["k0"]) - 0.5).astype(dt)
+        d = [None if a is None else torch.from_numpy(a).cuda() for a in (xt, xs, xn, f)]
+        runs = [sctl_amd.eval_device(name, *d, ctx=ctx).clone() for _ in range(3)]
+        tb = torch.int32 if dt == np.float32 else torch.int64
+        assert bool(torch.isfinite(runs[0]).all())
+        for r in runs[1:]:
+            assert int((r.view(tb) != runs[0].view(tb)).sum()) == 0, ("eval_device", name)
+        m = [sctl_amd.kernel_matrix_host(name, xt[:600], xs[:300], None if xn is None else xn[:100 * info["nd"]], ctx=ctx) for _ in range(2)]
+        assert np.array_equal(m[0].view(bits), m[1].view(bits)), ("kernel_matrix", name)
+        fl = (rng.random(int(cnt.sum()) * info["k0"]) - 0.5).astype(dt)
+        nl = (rng.random(int(cnt.sum()) * info["nd"]) - 0.5).astype(dt) if info["nd"] else None
+        u = [sctl_amd.eval_lists_host(name, *lists, xl, xl, nl, fl, ctx=ctx) for _ in range(2)]
+        assert np.all(np.isfinite(u[0])) and np.array_equal(u[0].view(bits), u[1].view(bits)), ("lists", name)
