@@ -31,24 +31,29 @@ bool use_mfma_f32() {
 int centered_pipe(int kernel_id, int real, int mode) {
   return ((kernel_id == Laplace3D_FxU::ID || kernel_id == Laplace3D_DxU::ID) && real == 1 /* SCTL_AMD_F32 */ && mode == 0 && use_mfma_f32()) ? 2 : 1;
 }
-// Targets per wave (= per workgroup) of that path: 128 (two per lane), or 256 = eight 32-column blocks for the matrix-core double layer, whose per-tile
-// staging (two contraction rows per source) is then shared by twice the pairs: 745 -> 675 ms at 2^21, where the single layer loses (445 -> 470 ms: more
-// near sources per wave, fewer waves per SIMD); A/B on one box, profiles/r03_ab_mfma_variants.txt.  SCTL_AMD_MFMA_CB=4 / 8 overrides (A/B runs).
+// Targets per wave (= per workgroup) of that path: 128 (two per lane) on the vector pipe, 256 = eight 32-column blocks for the matrix-core kernels, whose
+// per-tile staging (one or two contraction rows per source) is then shared by twice the pairs: double layer 745 -> 672 ms at 2^21; single layer 446 -> 426 ms
+// once it keeps three waves per SIMD at that size (centered_mfma_kernel.hpp).  A/B on one box, profiles/r03_ab_mfma_variants.txt, r03_ab_mfma_sl_occupancy.txt.
+// SCTL_AMD_MFMA_CB=4 / 8 overrides (A/B runs).
 int centered_targets_per_wave(int kernel_id, int real, int mode) {
   if (centered_pipe(kernel_id, real, mode) != 2) return 128;
   if (const char* e = std::getenv("SCTL_AMD_MFMA_CB")) {
     if (e[0] == '8') return 256;
     if (e[0] == '4') return 128;
   }
-  return kernel_id == Laplace3D_DxU::ID ? 256 : 128;
+  return 256;
 }
 namespace {
 template <class CP, class R, int MODE> void launch_centered(const EvalArgs<R>& a, dim3 grid, hipStream_t st) {
   if constexpr (std::is_same<R, float>::value && MODE == 0) {
     if (use_mfma_f32()) {   // (the caller sized grid.x with centered_targets_per_wave)
       constexpr bool DL = std::is_same<CP, CenteredDxU<float>>::value;
-      if (centered_targets_per_wave(CP::Ker::ID, 1, 0) == 256) hipLaunchKernelGGL((centered_mfma_f32_kernel<DL, 8>), grid, dim3(kWaveBlock), 0, st, a);
-      else hipLaunchKernelGGL((centered_mfma_f32_kernel<DL, 4>), grid, dim3(kWaveBlock), 0, st, a);
+      if (centered_targets_per_wave(CP::Ker::ID, 1, 0) == 256) {
+        if constexpr (DL) hipLaunchKernelGGL((centered_mfma_f32_kernel<true, 8>), grid, dim3(kWaveBlock), 0, st, a);
+        else hipLaunchKernelGGL(centered_mfma_fxu256_f32_kernel, grid, dim3(kWaveBlock), 0, st, a);
+      } else {
+        hipLaunchKernelGGL((centered_mfma_f32_kernel<DL, 4>), grid, dim3(kWaveBlock), 0, st, a);
+      }
       return;
     }
   }

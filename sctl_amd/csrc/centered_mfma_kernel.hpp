@@ -17,7 +17,7 @@
 //   double layer: ((x_t - x_s).n_s f_s) / r^3.  The numerator is a SECOND contraction against the SAME B operand: (x_t' - x_s').nf =
 //         sum over coordinates of (-nf/2)(-2 x_t') - x_s'.nf, i.e. a row A2 with the pieces of -nf_c / 2 in the coordinate slots, those of -x_s'.nf in the
 //         |x_s'|^2 slots and zeros in the |x_t'|^2 slots: two more MFMAs per 32 x 32 pairs, and the VALU is left with v_rsq_f32, y^3 and one FMA per pair.
-// A wave owns 128 targets as four column blocks (their B operands stay in registers for the whole kernel); the two half-waves see different source rows
+// A wave owns 256 targets as eight column blocks, or 128 as four (their B operands stay in registers for the whole kernel); the two half-waves see different source rows
 // of the same targets and add their sums at the end.  Staging, the far / near split, the exact masked near path, the carry of leftover far sources and
 // the (tile, split) mapping are those of centered_kernel.hpp.  fp32, MODE 0 only (more digits than the seed's go through the VALU kernel).
 #pragma once
@@ -72,8 +72,9 @@ __device__ __forceinline__ u32x4 b_tail(float tt) {
 #else
 #define SCTL_AMD_MFMA_ATTR
 #endif
-// CB: column blocks of 32 targets per wave (4: 128 targets, as the VALU kernel with two targets per lane)
-template <bool DL, int CB> __global__ void __launch_bounds__(kWaveBlock) SCTL_AMD_MFMA_ATTR centered_mfma_f32_kernel(const EvalArgs<float> a) {
+// CB: column blocks of 32 targets per wave (4: 128 targets, as the VALU kernel with two targets per lane; 8: 256).  STEP: keep ONE column block's MFMAs
+// ahead of the VALU work, no more (two sets of results in registers instead of one per block)
+template <bool DL, int CB, bool STEP> __device__ __forceinline__ void centered_mfma_f32_body(const EvalArgs<float>& a) {
   using R = float;
   constexpr int kColBlocks = CB, NQ = CB / 2;   // NQ: targets a lane owns (column blocks NQ h .. NQ h + NQ - 1)
   using Ker = typename std::conditional<DL, Laplace3D_DxU, Laplace3D_FxU>::type;
@@ -325,9 +326,7 @@ template <bool DL, int CB> __global__ void __launch_bounds__(kWaveBlock) SCTL_AM
             const f32x2 y = {__builtin_amdgcn_rsqf(r2[v]), __builtin_amdgcn_rsqf(r2[v + 1])};
             tacc[cb] += f32x2{fr[v >> 2][v & 3], fr[v >> 2][(v & 3) + 1]} * y;
           }
-#if defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_SL_STEP_FENCE)   // A/B builds: one column block's MFMAs ahead, no more (two result sets instead of four)
-          __builtin_amdgcn_sched_barrier(0);
-#endif
+          if constexpr (STEP) __builtin_amdgcn_sched_barrier(0);
           r2 = nxt;
         }
         asm volatile("" ::"v"(A0), "v"(A1));
@@ -392,6 +391,17 @@ template <bool DL, int CB> __global__ void __launch_bounds__(kWaveBlock) SCTL_AM
       else a.partial[(int64_t)split_idx * a.Nt + t] = sum;
     }
   }
+}
+
+// The kernels.  Single layer: 256 targets per wave with one column block's MFMAs ahead = 168 registers = three waves per SIMD (asked of the compiler: left to
+// itself it issues all eight blocks' first MFMAs up front, 186 registers, two waves) — 426 against 446 ms at 2^21 for the 128-target form, which loses 3 % under
+// the same fence and gains nothing from a fourth wave (profiles/r03_ab_mfma_sl_occupancy.txt).  Double layer: 256 targets per wave, two waves per SIMD
+// (centered.hip: centered_targets_per_wave).  The 128-target forms stay for A/B runs (SCTL_AMD_MFMA_CB=4).
+template <bool DL, int CB> __global__ void __launch_bounds__(kWaveBlock) SCTL_AMD_MFMA_ATTR centered_mfma_f32_kernel(const EvalArgs<float> a) {
+  centered_mfma_f32_body<DL, CB, false>(a);
+}
+__global__ void __launch_bounds__(kWaveBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) centered_mfma_fxu256_f32_kernel(const EvalArgs<float> a) {
+  centered_mfma_f32_body<false, 8, true>(a);
 }
 
 }  // namespace sctl_amd

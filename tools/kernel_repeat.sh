@@ -64,7 +64,7 @@ PY
 else
   echo "# tools/kernel_repeat.sh run: 24 launches of one kernel on one problem (2^17 targets x 2^16 sources, fp32), ANOTHER KERNEL between any two launches (POISON=1);"
   echo "# a run counts as off when any of its values differs from the value most runs give"
-  for k in ILb1ELi4E ILb1ELi8E ILb0ELi4E ILb0ELi8E; do for v in shipped nofence; do KERNEL=$k POISON=1 tools/ubench/kernel_repeat $D/$v.co; done; done
+  for k in ILb1ELi4E ILb1ELi8E ILb0ELi4E fxu256; do for v in shipped nofence; do KERNEL=$k POISON=1 tools/ubench/kernel_repeat $D/$v.co; done; done
   echo "# the double-layer / 128-target kernel of the no-fence build, its assembly patched with idle instructions"
   for v in nofence_pairnop nofence_allnop nofence_nearnop nofence_farnop; do POISON=1 tools/ubench/kernel_repeat $D/$v.co; done
   echo "# the no-fence kernel, launches back to back without another kernel in between, and with LDS / vector registers filled with NaN patterns in between"

@@ -2,7 +2,7 @@
 // launches (POISON=1; or fills every CU's LDS / most vector registers with a pattern: POISON=0x7fc00000, POISON_VGPR=1), so that every launch starts with cold
 // instruction caches and foreign machine state.  Written to pin down the run-to-run different near sums of centered_mfma_f32_kernel<true, 4> built WITHOUT the
 // near fence; tools/kernel_repeat.sh builds the code objects — the shipped kernels, the no-fence build, and that build's assembly with
-// s_nop instructions patched in — and runs them.  KERNEL = the template arguments of centered_mfma_f32_kernel<DL, CB> as mangled (default ILb1ELi4E).
+// s_nop instructions patched in — and runs them.  KERNEL = the template arguments of centered_mfma_f32_kernel<DL, CB> as mangled (default ILb1ELi4E), or fxu256 for centered_mfma_fxu256_f32_kernel.
 //   hipcc -O2 --offload-arch=gfx950 tools/ubench/kernel_repeat.cpp -o tools/ubench/kernel_repeat && POISON=1 tools/ubench/kernel_repeat a.co [b.co ...]
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -81,9 +81,10 @@ int main(int argc, char** argv) {
     CHECK(hipModuleLoad(&mod, argv[m]));
     // KERNEL: template arguments of centered_mfma_f32_kernel<DL, CB> as mangled, e.g. ILb1ELi4E (double layer, 128 targets per wave; the default)
     const char* targs = getenv("KERNEL") ? getenv("KERNEL") : "ILb1ELi4E";
-    const int per_wave = strstr(targs, "Li8E") ? 256 : 128;
+    const int per_wave = (strstr(targs, "Li8E") || !strcmp(targs, "fxu256")) ? 256 : 128;
     char sym[256];
-    snprintf(sym, sizeof(sym), "_ZN8sctl_amd24centered_mfma_f32_kernel%sEEvNS_8EvalArgsIfEE", targs);
+    if (!strcmp(targs, "fxu256")) snprintf(sym, sizeof(sym), "_ZN8sctl_amd31centered_mfma_fxu256_f32_kernelENS_8EvalArgsIfEE");   // the shipped single-layer kernel
+    else snprintf(sym, sizeof(sym), "_ZN8sctl_amd24centered_mfma_f32_kernel%sEEvNS_8EvalArgsIfEE", targs);
     CHECK(hipModuleGetFunction(&fn, mod, sym));
     std::vector<std::vector<uint32_t>> runs;
     CHECK(hipMemset(dv, 0, (size_t)REPS * Nt * 4));
