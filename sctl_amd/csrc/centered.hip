@@ -18,6 +18,18 @@ namespace sctl_amd {
     if (e_ != hipSuccess) return e_;  \
   } while (0)
 
+// Targets per lane of the vector-pipe kernel (centered_kernel.hpp): 64 T Morton-consecutive targets share a centre and every staged tile.  fp64: FOUR — half the
+// per-tile staging and LDS reads per pair for a somewhat larger cluster; the full-precision kernel still fits four waves per SIMD (125 registers), the others three.
+// A/B on one box (tools/ab_centered_T.py, profiles/r03_ab_centered_T.txt; T = 2 -> 4 -> 8): Laplace SL 2^20 x 2^20 405.4 -> 397.7 -> 405.9 ms at full precision,
+// 383.6 -> 369.5 -> 379.4 ms at 10 digits; double layer 563.9 -> 542.5 -> 534.1 ms; 2^18 x 2^18 and 2^20 x 2^14 level or 2-3 % faster; 2^17 x 2^20 +1 % at full
+// precision, -1.5 % at 10 digits.  fp32 keeps two: its far pairs are written as ONE packed stream over exactly two targets, and its default accuracy runs on the
+// matrix cores anyway.  (SCTL_AMD_EXP_CENTERED_T in an EXPERIMENTS build overrides both.)
+#if defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_CENTERED_T)
+template <class R> constexpr int kCenteredT = SCTL_AMD_EXP_CENTERED_T;
+#else
+template <class R> constexpr int kCenteredT = sizeof(R) == 8 ? 4 : 2;
+#endif
+
 namespace {
 // fp32 Laplace single and double layer at the seed's accuracy take the kernel whose contractions run on the bf16 matrix cores
 // (centered_mfma_kernel.hpp); SCTL_AMD_MFMA_F32=0 keeps the packed-VALU kernel (A/B runs and tests that compare the two)
@@ -36,7 +48,7 @@ int centered_pipe(int kernel_id, int real, int mode) {
 // once it keeps three waves per SIMD at that size (centered_mfma_kernel.hpp).  A/B on one box, profiles/r03_ab_mfma_variants.txt, r03_ab_mfma_sl_occupancy.txt.
 // SCTL_AMD_MFMA_CB=4 / 8 overrides (A/B runs).
 int centered_targets_per_wave(int kernel_id, int real, int mode) {
-  if (centered_pipe(kernel_id, real, mode) != 2) return 128;
+  if (centered_pipe(kernel_id, real, mode) != 2) return 64 * (real == 0 /* SCTL_AMD_F64 */ ? kCenteredT<double> : kCenteredT<float>);
   if (const char* e = std::getenv("SCTL_AMD_MFMA_CB")) {
     if (e[0] == '8') return 256;
     if (e[0] == '4') return 128;
@@ -58,9 +70,9 @@ template <class CP, class R, int MODE> void launch_centered(const EvalArgs<R>& a
     }
   }
 #if defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_FAR_UNR)   // A/B builds: far records per unrolled group
-  hipLaunchKernelGGL((centered_kernel<CP, R, MODE, 2, SCTL_AMD_EXP_FAR_UNR>), grid, dim3(kWaveBlock), 0, st, a);
+  hipLaunchKernelGGL((centered_kernel<CP, R, MODE, kCenteredT<R>, SCTL_AMD_EXP_FAR_UNR>), grid, dim3(kWaveBlock), 0, st, a);
 #else
-  hipLaunchKernelGGL((centered_kernel<CP, R, MODE, 2>), grid, dim3(kWaveBlock), 0, st, a);
+  hipLaunchKernelGGL((centered_kernel<CP, R, MODE, kCenteredT<R>>), grid, dim3(kWaveBlock), 0, st, a);
 #endif
 }
 }  // namespace
