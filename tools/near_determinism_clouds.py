@@ -1,6 +1,8 @@
+"""Run-to-run determinism of the tile-centred Laplace kernels through the ordinary device entry (per-call Morton sort, source splits, scatter back) on larger and
+less regular problems than tools/near_determinism.py: uniform 2^20 x 2^20, clustered, points on a sphere, many sources per target; fp32 on both pipes and fp64,
+single and double layer; three evaluations each, compared bit for bit."""
 import os, sys, numpy as np, torch
-sys.path.insert(0, '/root/repo')
-sys.path.insert(0, '/root/repo/tests')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sctl_amd
 g = torch.Generator(device='cuda').manual_seed(3)
 def clouds(kind, NT, NS):
