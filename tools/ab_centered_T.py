@@ -1,4 +1,5 @@
-"""A/B on ONE box: targets per lane of the vector-pipe tile-centred kernels (shipped 2 against builds with 4 / 8: tools/ab/libsctl_amd_T{4,8}.so, see
+"""A/B on ONE box: targets per lane of the vector-pipe tile-centred kernels, fp64 (the shipped library — four since late round 3, two when
+profiles/r03_ab_centered_T.txt was measured — against builds with -DSCTL_AMD_EXP_CENTERED_T=2 / 3 / 6 / 8: tools/ab/libsctl_amd_T<n>.so, see
 tools/ab_centered_T.sh) over kernels, sizes and accuracies: ms per evaluation, device-resident, targets unsorted (the per-call Morton sort included).
     SCTL_AMD_LIB=... python tools/ab_centered_T.py"""
 import os, sys, torch

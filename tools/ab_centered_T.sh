@@ -1,6 +1,7 @@
 #!/bin/bash
-# A/B on ONE box: the headline workload with two targets per lane (shipped: 128 per wave) against four (256 per wave: half the per-tile staging per pair, a larger
-# cluster) — tools/ab/libsctl_amd_T4.so: make -C sctl_amd/csrc EXTRA="-DSCTL_AMD_EXPERIMENTS -DSCTL_AMD_EXP_CENTERED_T=4" OUT=... OBJDIR=...
+# A/B on ONE box: the headline workload with the shipped targets per lane of the fp64 tile-centred kernels (four = 256 per wave since late round 3; two when
+# profiles/r03_ab_centered_T.txt was measured) against another count — tools/ab/libsctl_amd_T4.so: make -C sctl_amd/csrc
+# EXTRA="-DSCTL_AMD_EXPERIMENTS -DSCTL_AMD_EXP_CENTERED_T=4" OUT=... OBJDIR=... (likewise 2, 3, 6, 8; edit the list below)
 for rep in 1 2; do
   for lib in shipped T4; do
     if [ $lib = shipped ]; then unset SCTL_AMD_LIB; else export SCTL_AMD_LIB=$PWD/tools/ab/libsctl_amd_$lib.so; fi
