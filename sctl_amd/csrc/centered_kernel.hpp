@@ -325,22 +325,13 @@ __global__ void __launch_bounds__(kWaveBlock) SCTL_AMD_CENTERED_ATTR centered_ke
         for (int j = 0; j < T; j++) {
           const R d[3] = {xo[j][0] - q[0], xo[j][1] - q[1], xo[j][2] - q[2]};
           Ker::template pair<R, MODE, true>(acc[j], d, q, a.ctx, K);
-          // One pair after the other, never interleaved.  MEASURED on gfx950 (round 3, ROCm 7.2): without this fence ONE instantiation, the matrix-core
-          // double-layer kernel with 128 targets per wave (centered_mfma_kernel.hpp), gave near sums that differed from RUN TO RUN — lanes 48-63, the first of
-          // the lane's targets, only in waves that flush their near list between tiles; ~500 of 2^17 targets per run, errors up to O(1).  What is known
-          // (tools/kernel_repeat.sh, profiles/r03_kernel_repeat.txt: code objects of that build, its assembly patched, 24 launches each):
-          //   - it is a TIMING fault of the compiled code, not a data race of the source: `s_nop 3` behind every instruction of the kernel cures it (0 of 24
-          //     runs off), the same nops only inside or only outside the near-flush region do not; LDS or vector registers filled with NaN patterns between
-          //     launches change nothing and no NaN comes out, so nothing unwritten is read;
-          //   - it shows only when ANOTHER kernel ran since the last launch (any kernel; 24 of 24 runs off) and never in launches back to back — cold
-          //     instruction caches on a path that runs once per few hundred tiles;
-          //   - hipcc had interleaved the two targets' pairs into `v_rsq_f32 v34, v36 ; v_pk_mul_f32 v[36:37], ...` (the next instruction overwrites the
-          //     transcendental's source), the first suspect: one s_nop between the two does NOT cure it, and a microbenchmark of the pair is clean
-          //     (tools/ubench/trans_war.hip) — refuted;
-          //   - with the fence — other instruction order, same arithmetic — all four matrix-core kernels and the packed-VALU ones are bit-stable in that
-          //     detector and in tools/near_determinism.py (shortest near list, both targets-per-wave forms).
-          // The hardware mechanism is NOT identified.  What guards the shipped kernels is therefore a test, not a rule: tests/test_gpu_centered.py asks for
-          // bit-identical repeats with other kernels in between, for both layers, both fp32 pipes and fp64.
+          // One pair after the other.  Round 3 met near sums that differed from RUN TO RUN in one instantiation (the matrix-core double-layer kernel with 128 targets
+          // per wave, centered_mfma_kernel.hpp): whole contributions lost in lanes 48-63.  Round 4 pinned it down on that kernel's assembly
+          // (profiles/r04_near_fault_report.md): it needs the PACKED-fp32 and transcendental instructions the compiler interleaves in this loop — the SLP
+          // vectoriser packs the lane's targets — to meet another wave's bursts of v_rsq_f32 in the far loop; idle instructions cure it only behind every one
+          // of them, and an overwritten transcendental source (the first suspect) has nothing to do with it.  Two things keep it out: this unit is compiled
+          // with -fno-slp-vectorize (Makefile: no packed instruction in this loop; tools/check_isa_rules.py holds the assembly to it), which alone gives clean
+          // runs, and this fence, round 3's cure by experiment, which costs nothing.
 #if !(defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_NO_NEAR_FENCE))   // (the A/B build of tools/near_determinism.py)
           __builtin_amdgcn_sched_barrier(0);
 #endif

@@ -373,8 +373,8 @@ template <bool DL, int CB, bool STEP> __device__ __forceinline__ void centered_m
 
   // A precaution, not a measured fix: in the last call of run_far the B operands are dead after their last MFMA, and the register allocator handed them
   // to the VALU work five instructions behind it.  The compiler's hazard rules order a VALU write against an MFMA's C operand only; whether a write can
-  // reach an A / B register before an MFMA that waits in the matrix pipe has read it is not documented, and the fault first laid at this door turned out
-  // to be the near sums' (centered_kernel.hpp: flush_near).  Keeping every MFMA operand alive past the VALU batches that follow its last use costs
+  // reach an A / B register before an MFMA that waits in the matrix pipe has read it is not documented (the run-to-run different near sums first laid at
+  // this door were something else: centered_kernel.hpp, flush_near).  Keeping every MFMA operand alive past the VALU batches that follow its last use costs
   // nothing — the A rows to the end of their row block (above), the B columns to here — and tools/check_mfma_operands.py holds the assembly to it.
 #pragma unroll
   for (int cb = 0; cb < kColBlocks; cb++) asm volatile("" ::"v"(Bop[cb][0]), "v"(Bop[cb][1]));

@@ -5,6 +5,7 @@ import ctypes
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -189,3 +190,19 @@ def test_device_assembly_of_the_matrix_core_kernels_keeps_mfma_operands_untouche
     r = subprocess.run([os.sys.executable, os.path.join(ROOT, "tools", "check_mfma_operands.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert r.stdout.count("v_mfma, 0 operand write(s)") == 4, r.stdout      # the four matrix-core kernels (two shipped, two 128-target A/B forms) were found and are clean
+
+
+def test_device_assembly_of_every_shipped_kernel_keeps_the_isa_rules():
+    """tools/check_isa_rules.py over the assembly hipcc makes of EVERY translation unit of the library and of the test plugin, with the Makefile's own flags:
+    (A) a kernel that issues transcendental bursts has no packed-fp32 instruction in a loop of masked exact pairs — the combination the run-to-run different
+    near sums of round 3 needed (profiles/r04_near_fault_report.md); (B) no inline-asm body is the first reader of a transcendental or
+    matrix-core result.  And the rule bites: the frozen reproducer of that fault (the no-fence, SLP-vectorised build of the kernel that faulted) fails it."""
+    tool = os.path.join(ROOT, "tools", "check_isa_rules.py")
+    r = subprocess.run([sys.executable, tool, "--shipped"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+    lines = {l.split(":")[0]: l for l in r.stdout.splitlines()}
+    assert len(lines) >= 17 and "yukawa_kernel.s" in lines, r.stdout                 # every unit was looked at, the plugin included
+    m = re.search(r"\((\d+) with transcendental bursts", lines["centered.s"])
+    assert m and int(m.group(1)) >= 2, lines["centered.s"]                           # ... and the kernels rule A is about were recognised
+    bad = subprocess.run([sys.executable, tool, os.path.join(ROOT, "profiles", "r04_near_fault", "kernel_nofence.s")], capture_output=True, text=True)
+    assert bad.returncode == 1 and "rule A: 4 masked-pair loop(s) with packed fp32" in bad.stdout, bad.stdout + bad.stderr

@@ -189,17 +189,20 @@ def test_centred_fp32_contractions_on_the_matrix_cores_match_the_packed_valu_ker
                  f.astype(np.float64))
     e_m, e_v = rel_l2(u[sel], ref), rel_l2(u_valu[sel], ref)
     # (the double layer's signed 1/r^2 terms nearly cancel on some of these clouds: both kernels then sit further from the fp64 result, together)
-    assert e_m <= (1e-4 if name.endswith("FxU") else 1e-3) and e_m <= 3 * e_v + 1e-6, (name, kind, e_m, e_v)
+    assert e_m <= (1e-4 if name.endswith("FxU") else 1e-3) and e_m <= 2 * e_v + 5e-7, (name, kind, e_m, e_v)   # measured: e_m / e_v <= 1.3 except where both are a few fp32 ulps (7.8e-7 vs 2.9e-7 on the offset cloud)
     assert rel_l2(u, u_valu) <= (2e-5 if name.endswith("FxU") else 2e-4), (name, kind, rel_l2(u, u_valu))
 
 
 @pytest.mark.parametrize("kind", ["uniform", "clustered"])
 def test_centred_kernels_give_bit_identical_results_run_to_run(kind):
     """Every sum runs in a fixed order, so repeated evaluations of one problem must agree to the last bit.  Round 3 found near-field sums of one
-    instantiation of the fp32 double-layer kernels that did not (a timing fault of the compiled code in the path that flushes the list of near sources
-    between tiles; centered_kernel.hpp: flush_near) — a fault a tolerance test against the oracle sees only when it is large, and one that
-    shows only when OTHER kernels run between the launches: here the copy of every result and the fills of the next output do that.  Both fp32 pipes,
-    fp64, single and double layer; tools/near_determinism.py and tools/kernel_repeat.sh are the long forms."""
+    instantiation of the fp32 double-layer kernels that did not: whole contributions lost in lanes 48-63 when packed-fp32 and transcendental instructions
+    of the near flush met another wave's transcendental bursts (profiles/r04_near_fault_report.md) — a fault a tolerance test against the
+    oracle sees only when it is large, and one that shows only when OTHER kernels run between the launches: here the copy of every result and the fills of
+    the next output do that.  EVERY instantiation the library can launch is run: both fp32 pipes, the matrix-core kernels with 256 and with 128 targets per
+    wave (SCTL_AMD_MFMA_CB=4 selects the latter, the form that faulted), fp64, single and double layer; the clouds make waves flush their near list between
+    tiles (the clustered one in every wave).  tools/kernel_repeat_ranges.py on the frozen reproducer is the long form; tools/check_isa_rules.py (a CPU test)
+    holds the compiled code to what the analysis found."""
     import torch
     rng = np.random.default_rng(99)
     xt, xs = _clouds(kind, rng)
@@ -208,13 +211,21 @@ def test_centred_kernels_give_bit_identical_results_run_to_run(kind):
     for dt in (np.float32, np.float64):
         d = [torch.from_numpy(np.ascontiguousarray(a.ravel()).astype(dt)).cuda() for a in (xt, xs, xn, f)]
         bits = torch.int32 if dt == np.float32 else torch.int64
-        for env in (("1", "0") if dt == np.float32 else ("1",)):
-            os.environ["SCTL_AMD_MFMA_F32"] = env
+        # (pipe switch, targets-per-wave switch, targets per lane the plan must report)
+        cases = (("1", None, 4), ("1", "4", 2), ("0", None, 2)) if dt == np.float32 else (("1", None, 4),)
+        for mfma, cb, per_lane in cases:
+            os.environ["SCTL_AMD_MFMA_F32"] = mfma
+            if cb:
+                os.environ["SCTL_AMD_MFMA_CB"] = cb
             try:
                 for name in ("Laplace3D-FxU", "Laplace3D-DxU"):
-                    runs = [sctl_amd.eval_device(name, d[0], d[1], d[2] if name.endswith("DxU") else None, d[3]).clone() for _ in range(3)]
+                    pl = sctl_amd.plan(name, 1 if dt == np.float32 else 0, NT, NS)
+                    assert pl["path"] == "tile-centred" and pl["trg_per_lane"] == per_lane, (pl, mfma, cb)
+                    assert pl["pipe"].startswith("bf16 matrix cores") == (dt == np.float32 and mfma == "1"), pl
+                    runs = [sctl_amd.eval_device(name, d[0], d[1], d[2] if name.endswith("DxU") else None, d[3]).clone() for _ in range(6)]
                     assert bool(torch.isfinite(runs[0]).all())
                     for r in runs[1:]:
-                        assert int((r.view(bits) != runs[0].view(bits)).sum()) == 0, (name, dt.__name__, env, kind)
+                        assert int((r.view(bits) != runs[0].view(bits)).sum()) == 0, (name, dt.__name__, mfma, cb, kind)
             finally:
                 del os.environ["SCTL_AMD_MFMA_F32"]
+                os.environ.pop("SCTL_AMD_MFMA_CB", None)

@@ -110,6 +110,7 @@ def main():
         src = open(sys.argv[1]).read()
     else:
         flags = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "sctl_amd", "csrc"), "print-flags"], capture_output=True, text=True).stdout.split()
+        flags += subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "sctl_amd", "csrc"), "print-unit-flags", "UNIT=centered"], capture_output=True, text=True).stdout.split()
         with tempfile.TemporaryDirectory() as td:
             asm = os.path.join(td, "centered.s")
             subprocess.run(["/opt/rocm/bin/hipcc"] + flags + ["--offload-device-only", "-S", os.path.join(ROOT, "sctl_amd", "csrc", "centered.hip"), "-o", asm],

@@ -10,7 +10,7 @@ set -e
 cd "$(dirname "$0")/.."
 D=tools/ab/repeat
 LLVM=/opt/rocm/lib/llvm/bin
-FLAGS="$(make -s -C sctl_amd/csrc print-flags) --offload-device-only -S"
+FLAGS="$(make -s -C sctl_amd/csrc print-flags) $(make -s -C sctl_amd/csrc print-unit-flags UNIT=centered) --offload-device-only -S"
 co() { $LLVM/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c $D/$1.s -o $D/$1.o && $LLVM/ld.lld -shared $D/$1.o -o $D/$1.co && rm -f $D/$1.o; }
 if [ "$1" = build ]; then
   mkdir -p $D

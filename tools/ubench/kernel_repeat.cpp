@@ -114,6 +114,19 @@ int main(int argc, char** argv) {
       nonfinite += ((ref[i] >> 23) & 0xff) == 0xff;
     }
     for (int r = 0; r < REPS; r++) { long n = 0; for (int64_t i = 0; i < Nt; i++) n += runs[r][i] != ref[i]; bad_values += n; bad_runs += n > 0; }
+    if (getenv("DETAIL")) {   // where in the wave the off values sit (position = target index mod targets per wave) and what a few of them look like
+      std::vector<long> hist(per_wave, 0);
+      int shown = 0;
+      for (int r = 0; r < REPS; r++)
+        for (int64_t i = 0; i < Nt; i++)
+          if (runs[r][i] != ref[i]) {
+            hist[i % per_wave]++;
+            if (shown < 12) { float a, b; memcpy(&a, &ref[i], 4); memcpy(&b, &runs[r][i], 4); printf("      run %2d target %6ld (wave %4ld, position %3ld): %.8e instead of %.8e, difference %.3e\n", r, (long)i, (long)(i / per_wave), (long)(i % per_wave), b, a, b - a); shown++; }
+          }
+      printf("      off values by position in the wave:");
+      for (int k = 0; k < per_wave; k++) if (hist[k]) printf(" %d:%ld", k, hist[k]);
+      printf("\n");
+    }
     long vs_first = -1;
     if (!first.empty()) { vs_first = 0; for (int64_t i = 0; i < Nt; i++) vs_first += ref[i] != first[0][i]; }
     printf("%-28s %-10s %d runs of 2^17 x 2^16: runs with a value off the majority result %ld, such values %ld, non-finite %ld%s\n", argv[m], targs, REPS, bad_runs, bad_values, nonfinite,
