@@ -21,6 +21,7 @@
 #ifndef SCTL_AMD_COMM_HPP_
 #define SCTL_AMD_COMM_HPP_
 
+#include <cstdio>
 #include <cstdlib>
 #include <initializer_list>
 #include <memory>
@@ -77,7 +78,15 @@ class Comm {
     const long explicit_size = Env({"SCTL_AMD_WORLD_SIZE"}, 0);
     const long size = explicit_size > 0 ? explicit_size : Env({"WORLD_SIZE", "OMPI_COMM_WORLD_SIZE", "PMI_SIZE", "SLURM_NTASKS"}, 1);
     if (size <= 1) return Comm();
-    if (explicit_size <= 1 && !(std::getenv("MASTER_ADDR") && std::getenv("MASTER_PORT"))) return Comm();   // no rendezvous named: independent tasks
+    if (explicit_size <= 1 && !(std::getenv("MASTER_ADDR") && std::getenv("MASTER_PORT"))) {
+      // A launcher reports several tasks but names no rendezvous: they run INDEPENDENTLY, each on its own sources — under the reference's contract
+      // (the potential from ALL ranks' sources, fmm-wrapper.txx:504-561) that is another answer, so it is said once, loudly.
+      if (Env({"SCTL_AMD_COMM_QUIET"}, 0) == 0)
+        std::fprintf(stderr, "sctl_amd: %ld tasks detected (launcher environment) but no rendezvous is named: every task evaluates on its own, NOT rank-parallel. "
+                             "Set MASTER_ADDR and MASTER_PORT (or SCTL_AMD_WORLD_SIZE / SCTL_AMD_RANK) for one rank-parallel evaluation, SCTL_AMD_COMM=0 to "
+                             "run independent tasks without this message.\n", size);
+      return Comm();
+    }
     const long rank = Env({"SCTL_AMD_RANK", "RANK", "OMPI_COMM_WORLD_RANK", "PMI_RANK", "SLURM_PROCID"}, 0);
     const long local = Env({"SCTL_AMD_LOCAL_RANK", "LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "SLURM_LOCALID"}, rank);
     const int ndev = sctl_amd_device_count();

@@ -39,17 +39,9 @@ template <class R> struct VecOf;
 template <> struct VecOf<double> { typedef double type __attribute__((ext_vector_type(2))); static constexpr int N = 2; };
 template <> struct VecOf<float> { typedef float type __attribute__((ext_vector_type(4))); static constexpr int N = 4; };
 
-// sources per unrolled loop body: 4-8 independent accumulation chains in flight per lane
-#if defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_UNROLL)   // timing experiments only (tools/)
-template <int T, int K1> struct UnrollOf { static constexpr int value = SCTL_AMD_EXP_UNROLL; };
-#else
+// sources per unrolled loop body: 4-8 independent accumulation chains in flight per lane (other unroll factors and forced occupancies were timed in rounds 1-3:
+// profiles/r03_ab_helmholtz_unroll.txt, r03_ab_centered_occupancy.txt)
 template <int T, int K1> struct UnrollOf { static constexpr int value = (T * K1 >= 8) ? 1 : ((T * K1 >= 3) ? 2 : 4); };
-#endif
-#if defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_WAVES)
-#define SCTL_AMD_EVAL_ATTR __attribute__((amdgpu_waves_per_eu(SCTL_AMD_EXP_WAVES, SCTL_AMD_EXP_WAVES)))
-#else
-#define SCTL_AMD_EVAL_ATTR
-#endif
 
 template <class R> __device__ __forceinline__ R max_finite();
 template <> __device__ __forceinline__ double max_finite<double>() { return 1.7976931348623157e308; }
@@ -58,7 +50,7 @@ __device__ __forceinline__ double fabs_(double x) { return __builtin_fabs(x); }
 __device__ __forceinline__ float fabs_(float x) { return __builtin_fabsf(x); }
 
 template <class Ker, class R, int MODE, int T>
-__global__ void __launch_bounds__(kBlock) SCTL_AMD_EVAL_ATTR eval_kernel(const EvalArgs<R> a) {
+__global__ void __launch_bounds__(kBlock) eval_kernel(const EvalArgs<R> a) {
   constexpr int K0 = Ker::K0, K1 = Ker::K1, ND = Ker::ND, NREC = Ker::NREC;
   using V = typename VecOf<R>::type;
   constexpr int VN = VecOf<R>::N;

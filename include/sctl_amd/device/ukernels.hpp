@@ -102,11 +102,7 @@ template <class R> struct DefaultConsts {
 };
 // The Helmholtz kernel runs on the modes' unnormalised reciprocal square roots too (rsqrt_scaled below: C / r with C = 2 for MODE 1, A = 2.6666666 for
 // MODE 2): the amplitude's C goes into the scale, and the distance comes out as r2 (C / r) = C r at the price of the normalised one.  C by mode:
-#if defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_HALLEY)
-constexpr double helmholtz_dist_factor(int mode) { return mode == 1 ? 2.0 : 1.0; }
-#else
 constexpr double helmholtz_dist_factor(int mode) { return mode == 1 ? 2.0 : mode == 2 ? 0x1.5555550000000p+1 : 1.0; }
-#endif
 template <class R> struct HelmholtzConsts;
 template <> struct HelmholtzConsts<float> {          // fp32: libm sincosf / expf
   static constexpr int LDS_DOUBLES = 0;
@@ -139,11 +135,7 @@ template <> struct HelmholtzConsts<double> {         // fp64: table-driven e^{ik
   // (a Consts type constructible from (double*, int, const KerCtx&[, int mode]) is handed the scratch capacity, the launch's context and its accuracy mode: make_consts below)
   __device__ __forceinline__ HelmholtzConsts(double* lds, int lds_doubles, const KerCtx& ctx) : HelmholtzConsts(lds, lds_doubles, ctx, 0) {}
   __device__ __forceinline__ HelmholtzConsts(double* lds, int lds_doubles, const KerCtx& ctx, int mode) : table(lds), cdist(helmholtz_dist_factor(mode)), cinv(1.0 / helmholtz_dist_factor(mode)) {
-#ifdef SCTL_AMD_EXP_HELMHOLTZ_TWO_REDUCTIONS       // A/B switch of tools/ (never defined in the shipped library)
-    one_reduction = false;
-#else
-    one_reduction = lds_doubles >= fastmath::kCexpTableDoubles && fastmath::CexpCoeffsK::usable(ctx.v[0], -ctx.v[1]);
-#endif
+    one_reduction = lds_doubles >= fastmath::kCexpTableDoubles && fastmath::CexpCoeffsK::usable(ctx.v[0], -ctx.v[1]);   // (+17 % over two reductions: profiles/r03_ab_helmholtz_one_reduction.txt)
     {
       const fastmath::Coeffs full;                   // the table-free polynomials, used here only
       if (one_reduction) fastmath::fill_cexp_tables(lds, (int)threadIdx.x, (int)blockDim.x, ctx.v[0], -ctx.v[1], full, fastmath::TabCoeffs());
@@ -269,20 +261,13 @@ template <bool MASKED> __device__ __forceinline__ double rsqrt_cubic83(double r2
 // fp32 never runs MODE 2 (capi.hip: mode_for); kept consistent with the shared scale factor
 template <bool MASKED> __device__ __forceinline__ float rsqrt_cubic83(float r2, const RsqConst<float>& K) { return rsqrt_masked<1, MASKED>(r2, K) * (float)cubic83_factor(1); }
 // 1/r times the factor Ker::acc_factor(MODE) accounts for, for a kernel whose terms all carry the same power of 1/r
-#if defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_HALLEY)   // A/B build of tools/ab_cubic83.sh: MODE 2 keeps the five-instruction Halley step
-template <int MODE, bool MASKED, class R> __device__ __forceinline__ R rsqrt_scaled(R r2, const RsqConst<R>& K) {
-  if constexpr (MODE == 1) return rsqrt_newton2<MASKED>(r2, K);
-  else return rsqrt_masked<MODE, MASKED>(r2, K);
-}
-constexpr double rsqrt_scaled_factor(int mode, int p) { return mode == 1 ? newton2_factor(p) : 1; }
-#else
+// (A/B against the five-instruction Halley step, one box: profiles/r03_ab_cubic83.txt, +11 % on the headline)
 template <int MODE, bool MASKED, class R> __device__ __forceinline__ R rsqrt_scaled(R r2, const RsqConst<R>& K) {
   if constexpr (MODE == 1) return rsqrt_newton2<MASKED>(r2, K);
   else if constexpr (MODE == 2) return rsqrt_cubic83<MASKED>(r2, K);
   else return rsqrt_masked<0, MASKED>(r2, K);
 }
 constexpr double rsqrt_scaled_factor(int mode, int p) { return mode == 1 ? newton2_factor(p) : mode == 2 ? cubic83_factor(p) : 1; }
-#endif
 // r^-3 and r^-5 for the kernels that need only that power (double layer, gradient, stresslet, traction).  MODE 2 does not cube the refined 1/r:
 // (1 - e)^(-3/2) = 1 + 3/2 e + 15/8 e^2 + ... and (1 - e)^(-5/2) = 1 + 5/2 e + 35/8 e^2 + ... are again monic quadratics in w = r2 y0^2 up to a
 // factor, 15/8 ((w - 7/5)^2 + 28/75) and 35/8 ((w - 9/7)^2 + 36/245), so
@@ -301,22 +286,15 @@ template <bool MASKED> __device__ __forceinline__ double rsqrt5_cubic(double r2,
   const double z = __builtin_fma(r2, s, -K.c5);
   return (y * (s * s)) * __builtin_fma(z, z, K.k5);
 }
-#if defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_HALLEY)
-constexpr double rsqrt_pow_factor(int mode, int p) { return rsqrt_scaled_factor(mode, p); }
-#else
 constexpr double rsqrt_pow_factor(int mode, int p) { return mode == 2 ? (p == 1 ? cubic83_factor(1) : p == 3 ? kCubic3A : kCubic5A) : rsqrt_scaled_factor(mode, p); }
-#endif
 // r^-P times rsqrt_pow_factor(MODE, P), P = 3 or 5
 template <int MODE, int P, bool MASKED, class R> __device__ __forceinline__ R rsqrt_pow_scaled(R r2, const RsqConst<R>& K) {
   static_assert(P == 3 || P == 5, "powers 3 and 5");
-#if !(defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_HALLEY))
   if constexpr (MODE == 2 && std::is_same<R, double>::value) return P == 3 ? rsqrt3_cubic<MASKED>(r2, K) : rsqrt5_cubic<MASKED>(r2, K);
   else if constexpr (MODE == 2) {   // fp32 never runs MODE 2 (capi.hip: mode_for); kept consistent with the shared scale factor
     const R y = rsqrt_masked<1, MASKED>(r2, K), y2 = y * y;
     return (P == 3 ? y2 * y : y2 * y2 * y) * R(rsqrt_pow_factor(2, P));
-  } else
-#endif
-  {
+  } else {
     const R y = rsqrt_scaled<MODE, MASKED>(r2, K), y2 = y * y;
     return P == 3 ? y2 * y : y2 * y2 * y;
   }

@@ -153,21 +153,14 @@ struct Plan {
 Plan make_plan(const KernelEntry& k, int real, int64_t Nt, int64_t Ns) {
   // workgroups wanted: 8 per CU (32 waves) — measured +4 % over 4 per CU at Nt = 2^17, Ns = 2^20 and on the Stokeslet at
   // 2^18 — except for tiny problems, which are launch-bound and lose time to the extra partial sums
-#if defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_SMALL_WANT)   // A/B builds: workgroups per CU for small problems
-  const int64_t want = (int64_t)cu_count() * ((double)Nt * (double)Ns < 2147483648.0 ? SCTL_AMD_EXP_SMALL_WANT : 8);
-#else
+  // (2 / 4 / 6 / 8 per CU for small problems, and two targets per lane from other sizes on: profiles/r02_small_problem_plans.txt)
   const int64_t want = (int64_t)cu_count() * ((double)Nt * (double)Ns < 2147483648.0 ? 4 : 8);
-#endif
   Plan p{};
   // Two targets per lane halve the LDS reads per pair and double the independent chains: 5-7 % faster than one target
   // per lane from Nt = 2^16 up on every kernel (Stokeslet 2^18: 56.2 vs 59.7 ms; traction kernel 72.5 vs 77.9 ms), with
   // the source range split further to keep the chip full; at Nt <= 2^14 one target per lane wins (0.18 vs 0.20 ms).
   (void)k;
-#if defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_T2_FROM)   // A/B builds: the target count from which a lane takes two targets
-  const int t = (Nt >= SCTL_AMD_EXP_T2_FROM) ? 2 : 1;
-#else
   const int t = (Nt >= 32768) ? 2 : 1;
-#endif
   p.t_idx = (t == 1) ? 0 : 1;
   p.wg_x = (Nt + (int64_t)kBlock * t - 1) / ((int64_t)kBlock * t);
   if (p.wg_x < 1) p.wg_x = 1;
@@ -181,7 +174,6 @@ Plan make_plan(const KernelEntry& k, int real, int64_t Nt, int64_t Ns) {
   // past its 4 MB L2 and nothing left to even out the CUs.  With one split's source data <= 2 MB, the splits a multiple of 8 and each split
   // owned by one XCD (eval_kernel.hpp) the launch has 8-32 x more workgroups than the chip holds at once: 1.3-2.8 % faster (Stokeslet 2^18,
   // SL+DL 2^20, Helmholtz 2^20).  Bounded: at most 64 splits, at most 4 GB of partial sums; problems under 2^34 pairs keep the old plan.
-#if !(defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_NO_L2_SPLITS))   // (the A/B build of tools/ab_eval_l2_splits.sh switches the rule off)
   if ((double)Nt * (double)Ns >= 17179869184.0) {
     const int64_t rs = (real == SCTL_AMD_F64 ? 8 : 4);
     const int64_t src_bytes = Ns * (3 + k.nd + k.k0) * rs;
@@ -194,7 +186,6 @@ Plan make_plan(const KernelEntry& k, int real, int64_t Nt, int64_t Ns) {
     if (s >= 8) s = (s + 7) / 8 * 8;      // in eights also when the workgroup count, not the L2, asked for the splits (the XCD mapping needs it)
     if (s > ntile) s = ntile;
   }
-#endif
   int64_t tiles_per = (ntile + s - 1) / s;
   if (tiles_per < 1) tiles_per = 1;
   p.chunk = tiles_per * kTile;
@@ -347,13 +338,8 @@ inline size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
 hipError_t upload(void* dst, const void* src, size_t bytes, PinnedBuf& stage, hipStream_t st) {
   if (!bytes) return hipSuccess;
   char* q = stage.take(bytes);
-#if defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_NO_STAGING)   // A/B build of tools/h2d_in_library.py: copy straight from the caller's pageable array
-  (void)q;
-  return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
-#else
-  std::memcpy(q, src, bytes);
+  std::memcpy(q, src, bytes);   // (against a copy straight from the caller's pageable array: profiles/r01b_host_entry.txt)
   return hipMemcpyAsync(dst, q, bytes, hipMemcpyHostToDevice, st);
-#endif
 }
 
 // grow-only device buffer and the per-(thread, device) cache of the one-shot host entry

@@ -23,12 +23,8 @@ namespace sctl_amd {
 // A/B on one box (tools/ab_centered_T.py, profiles/r03_ab_centered_T.txt; T = 2 -> 4 -> 8): Laplace SL 2^20 x 2^20 405.4 -> 397.7 -> 405.9 ms at full precision,
 // 383.6 -> 369.5 -> 379.4 ms at 10 digits; double layer 563.9 -> 542.5 -> 534.1 ms; 2^18 x 2^18 and 2^20 x 2^14 level or 2-3 % faster; 2^17 x 2^20 +1 % at full
 // precision, -1.5 % at 10 digits.  fp32 keeps two: its far pairs are written as ONE packed stream over exactly two targets, and its default accuracy runs on the
-// matrix cores anyway.  (SCTL_AMD_EXP_CENTERED_T in an EXPERIMENTS build overrides both.)
-#if defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_CENTERED_T)
-template <class R> constexpr int kCenteredT = SCTL_AMD_EXP_CENTERED_T;
-#else
+// matrix cores anyway.
 template <class R> constexpr int kCenteredT = sizeof(R) == 8 ? 4 : 2;
-#endif
 
 namespace {
 // fp32 Laplace single and double layer at the seed's accuracy take the kernel whose contractions run on the bf16 matrix cores
@@ -60,7 +56,8 @@ template <class CP, class R, int MODE> void launch_centered(const EvalArgs<R>& a
   if constexpr (std::is_same<R, float>::value && MODE == 0) {
     if (use_mfma_f32()) {   // (the caller sized grid.x with centered_targets_per_wave)
       constexpr bool DL = std::is_same<CP, CenteredDxU<float>>::value;
-      if (centered_targets_per_wave(CP::Ker::ID, 1, 0) == 256) {
+      const int per_wave = centered_targets_per_wave(CP::Ker::ID, 1, 0);
+      if (per_wave == 256) {
         if constexpr (DL) hipLaunchKernelGGL((centered_mfma_f32_kernel<true, 8>), grid, dim3(kWaveBlock), 0, st, a);
         else hipLaunchKernelGGL(centered_mfma_fxu256_f32_kernel, grid, dim3(kWaveBlock), 0, st, a);
       } else {
@@ -69,11 +66,7 @@ template <class CP, class R, int MODE> void launch_centered(const EvalArgs<R>& a
       return;
     }
   }
-#if defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_FAR_UNR)   // A/B builds: far records per unrolled group
-  hipLaunchKernelGGL((centered_kernel<CP, R, MODE, kCenteredT<R>, SCTL_AMD_EXP_FAR_UNR>), grid, dim3(kWaveBlock), 0, st, a);
-#else
   hipLaunchKernelGGL((centered_kernel<CP, R, MODE, kCenteredT<R>>), grid, dim3(kWaveBlock), 0, st, a);
-#endif
 }
 }  // namespace
 
@@ -93,9 +86,6 @@ void centered_plan(int64_t Nt, int64_t Ns, int cus, int src_bytes, int* T, int* 
   int64_t s = (want + wg_x - 1) / wg_x;
   const int64_t s_l2 = (Ns * src_bytes + (2 << 20) - 1) / (2 << 20);
   if (s < s_l2) s = s_l2;
-#ifdef SCTL_AMD_EXPERIMENTS   // timing experiments only (tools/): never defined for the shipped library
-  if (const char* e = std::getenv("SCTL_AMD_EXPERIMENT_SPLITS")) s = std::atoi(e);
-#endif
   if (s > ntile / 64) s = ntile / 64;      // at least 64 tiles (4096 sources) per split
   if (s > 8) s = (s + 7) & ~(int64_t)7;    // the XCD-aware mapping needs a multiple of 8
   if (s > 64) s = 64;
@@ -163,9 +153,6 @@ hipError_t eval_centered_t(int64_t Nt, int64_t Ns, const R* xt, const R* xs, con
   a.Nt = Nt; a.Ns = Ns; a.xt = xts; a.xs = xs; a.xn = xn; a.f = f; a.v_trg = outs; a.partial = nullptr;
   a.chunk = chunk; a.scale = scale;
   a.ctx.v[0] = kNearFactor2;
-#ifdef SCTL_AMD_EXPERIMENTS   // timing experiments only (tools/near_factor.py); values below kNearFactor2 void the accuracy bound
-  if (const char* e = std::getenv("SCTL_AMD_EXPERIMENT_NEAR_FACTOR")) a.ctx.v[0] = std::atof(e);
-#endif
   a.partial = partial;
   const int64_t per_wave = centered_targets_per_wave(CP::Ker::ID, sizeof(R) == 8 ? 0 : 1, mode);
   const dim3 grid((unsigned)((Nt + per_wave - 1) / per_wave), (unsigned)splits);

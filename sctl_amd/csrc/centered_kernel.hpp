@@ -105,6 +105,26 @@ __device__ __forceinline__ f32x2 pk_fma_lo_hi(f32x2 m, f32x2 g) {
   return r;
 }
 
+// The target side of a far pair: -2 x_t' and |x_t'|^2 of the lane's T targets.  fp32 with two targets keeps them as {target 0, target 1} register pairs as
+// ONLY: built inside the far loop from elements of two arrays, the pairs kept those arrays in scratch memory (32 bytes per lane,
+// re-read for every tile).
+template <class R, int T> struct FarTargets {
+  R m2x[T][3], tt[T];
+  __device__ __forceinline__ void set(int j, const R (&p)[3], R t2) {
+    tt[j] = t2;
+#pragma unroll
+    for (int k = 0; k < 3; k++) m2x[j][k] = R(-2) * p[k];
+  }
+};
+template <> struct FarTargets<float, 2> {
+  f32x2 mp[3], tp;
+  __device__ __forceinline__ void set(int j, const float (&p)[3], float t2) {
+    tp[j] = t2;
+#pragma unroll
+    for (int k = 0; k < 3; k++) mp[k][j] = -2.0f * p[k];
+  }
+};
+
 // What a kernel needs to run on the centred path (scalar potentials, K1 = 1): besides {x', y', z', |x_s'|^2} a far source
 // carries XW more reals, written by put_extra / put_null and read once per source by load_extra; far_pair is the pair
 // evaluation from the centred quantities.  Near sources go through the kernel's own exact pair (Ker::pack / Ker::pair).
@@ -133,18 +153,18 @@ template <class R> struct CenteredFxU {      // u += f / r
     acc = fma_(e.f, rsqrt_scaled<MODE, false>(r2, K), acc);   // MODE 1: 2/r, MODE 2: (8/3)/r, as Ker::pair (acc_factor)
   }
   // all T targets of the lane against one far source
-  template <int MODE, int T> static __device__ __forceinline__ void far_pairs(R (&acc)[T], const R (&m2x)[T][3], const R (&tt)[T], const R (&b)[4], const Extra& e,
+  template <int MODE, int T> static __device__ __forceinline__ void far_pairs(R (&acc)[T], const FarTargets<R, T>& tg, const R (&b)[4], const Extra& e,
                                                                                 const RsqConst<R>& K) {
     if constexpr (std::is_same<R, float>::value && T == 2) {
-      f32x2 r2 = pk_add_hi(f32x2{tt[0], tt[1]}, f32x2{b[2], b[3]});
-      r2 = f32x2{m2x[0][2], m2x[1][2]} * f32x2{b[2], b[2]} + r2;
-      r2 = f32x2{m2x[0][1], m2x[1][1]} * f32x2{b[1], b[1]} + r2;
-      r2 = f32x2{m2x[0][0], m2x[1][0]} * f32x2{b[0], b[0]} + r2;
+      f32x2 r2 = pk_add_hi(tg.tp, f32x2{b[2], b[3]});
+      r2 = tg.mp[2] * f32x2{b[2], b[2]} + r2;
+      r2 = tg.mp[1] * f32x2{b[1], b[1]} + r2;
+      r2 = tg.mp[0] * f32x2{b[0], b[0]} + r2;
       const f32x2 a = f32x2{acc[0], acc[1]} + f32x2{e.f, e.f2} * rsqrt_pair<MODE>(r2);
       acc[0] = a[0]; acc[1] = a[1];
     } else {
 #pragma unroll
-      for (int j = 0; j < T; j++) far_pair<MODE>(acc[j], m2x[j], tt[j], b, e, K);
+      for (int j = 0; j < T; j++) far_pair<MODE>(acc[j], tg.m2x[j], tg.tt[j], b, e, K);
     }
   }
 };
@@ -171,11 +191,11 @@ template <class R> struct CenteredDxU {      // u += ((x_t - x_s).n f) / r^3, wi
     const R dn = fma_(m2x[0], e.g[0], fma_(m2x[1], e.g[1], fma_(m2x[2], e.g[2], e.g[3])));
     acc = fma_(dn, y3, acc);
   }
-  template <int MODE, int T> static __device__ __forceinline__ void far_pairs(R (&acc)[T], const R (&m2x)[T][3], const R (&tt)[T], const R (&b)[4], const Extra& e,
+  template <int MODE, int T> static __device__ __forceinline__ void far_pairs(R (&acc)[T], const FarTargets<R, T>& tg, const R (&b)[4], const Extra& e,
                                                                                 const RsqConst<R>& K) {
     if constexpr (std::is_same<R, float>::value && T == 2) {
-      const f32x2 mx = {m2x[0][0], m2x[1][0]}, my = {m2x[0][1], m2x[1][1]}, mz = {m2x[0][2], m2x[1][2]};
-      f32x2 r2 = pk_add_hi(f32x2{tt[0], tt[1]}, f32x2{b[2], b[3]});
+      const f32x2 mx = tg.mp[0], my = tg.mp[1], mz = tg.mp[2];
+      f32x2 r2 = pk_add_hi(tg.tp, f32x2{b[2], b[3]});
       r2 = mz * f32x2{b[2], b[2]} + r2;
       r2 = my * f32x2{b[1], b[1]} + r2;
       r2 = mx * f32x2{b[0], b[0]} + r2;
@@ -187,20 +207,16 @@ template <class R> struct CenteredDxU {      // u += ((x_t - x_s).n f) / r^3, wi
       acc[0] = a[0]; acc[1] = a[1];
     } else {
 #pragma unroll
-      for (int j = 0; j < T; j++) far_pair<MODE>(acc[j], m2x[j], tt[j], b, e, K);
+      for (int j = 0; j < T; j++) far_pair<MODE>(acc[j], tg.m2x[j], tg.tt[j], b, e, K);
     }
   }
 };
 
 // a.xt: Morton-sorted targets; a.v_trg / a.partial: indexed like a.xt (the caller scatters back).
-// (asking the compiler for 5-6 waves/SIMD instead of the 4 its 118 VGPRs allow costs 1-3 %: measured 464-471 vs 458 ms)
-#if defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_CENTERED_WAVES)   // A/B builds of tools/ab_centered_occupancy.sh: waves per SIMD asked of the compiler
-#define SCTL_AMD_CENTERED_ATTR __attribute__((amdgpu_waves_per_eu(SCTL_AMD_EXP_CENTERED_WAVES, SCTL_AMD_EXP_CENTERED_WAVES)))
-#else
-#define SCTL_AMD_CENTERED_ATTR
-#endif
+// (asking the compiler for 5-6 waves/SIMD instead of the 4 its registers allow, or unrolling the far loop by 2 or 8 instead of 4, costs 0-3 %:
+// profiles/r03_ab_centered_occupancy.txt)
 template <class CP, class R, int MODE, int T, int UNR = 4>
-__global__ void __launch_bounds__(kWaveBlock) SCTL_AMD_CENTERED_ATTR centered_kernel(const EvalArgs<R> a) {
+__global__ void __launch_bounds__(kWaveBlock) centered_kernel(const EvalArgs<R> a) {
   using V = typename Rec4<R>::V;
   constexpr int NW = Rec4<R>::NW;
   using Ker = typename CP::Ker;
@@ -222,13 +238,11 @@ __global__ void __launch_bounds__(kWaveBlock) SCTL_AMD_CENTERED_ATTR centered_ke
   // [k * gridDim.y / 8, (k + 1) * gridDim.y / 8) for ALL tiles: one split (2 MB at 2^20 sources / 16) stays in its 4 MB L2 while the
   // tiles stream by.  Same work per XCD; the results do not depend on the mapping.
   unsigned tile_idx = blockIdx.x, split_idx = blockIdx.y;
-#if !(defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_PLAIN_MAP))   // (the A/B build of tools/ab_xcd_map.sh)
-  if ((gridDim.y & 7u) == 0) {
+  if ((gridDim.y & 7u) == 0) {   // (A/B against the plain mapping: profiles/r02_ab_xcd_map.txt)
     const unsigned b = blockIdx.y * gridDim.x + blockIdx.x, xcd = b & 7u, j = b >> 3, per = gridDim.y >> 3;
     tile_idx = j % gridDim.x;
     split_idx = xcd * per + j / gridDim.x;
   }
-#endif
   const int64_t tbase = (int64_t)tile_idx * (kWaveBlock * T);
   const typename Ker::template Consts<R> K(nullptr);
 
@@ -251,14 +265,14 @@ __global__ void __launch_bounds__(kWaveBlock) SCTL_AMD_CENTERED_ATTR centered_ke
 #pragma unroll
     for (int k = 0; k < 3; k++) c[k] = uniform_(R(0.5) * wave_min(lo[k]) + R(0.5) * wave_max(hi[k]));
   }
-  R m2x[T][3], tt[T], rt2 = 0;
+  FarTargets<R, T> tg;
+  R rt2 = 0;
 #pragma unroll
   for (int j = 0; j < T; j++) {
     const R p[3] = {xt[j][0] - c[0], xt[j][1] - c[1], xt[j][2] - c[2]};
-    tt[j] = len2(p);
-    rt2 = (tt[j] > rt2) ? tt[j] : rt2;
-#pragma unroll
-    for (int k = 0; k < 3; k++) m2x[j][k] = R(-2) * p[k];
+    const R t2 = len2(p);
+    rt2 = (t2 > rt2) ? t2 : rt2;
+    tg.set(j, p, t2);
   }
   rt2 = uniform_(wave_max(rt2));
   const R near_r2 = R(a.ctx.v[0]) * rt2;   // ctx.v[0] = kNearFactor2; NaN coordinates fail every comparison => "near" => exact path
@@ -380,7 +394,7 @@ __global__ void __launch_bounds__(kWaveBlock) SCTL_AMD_CENTERED_ATTR centered_ke
         R b[4];
         Rec4<R>::get(farB + (s + u) * NW, b);
         const typename CP::Extra e = CP::load_extra(farX, s + u);
-        CP::template far_pairs<MODE, T>(tacc, m2x, tt, b, e, K.rsq);
+        CP::template far_pairs<MODE, T>(tacc, tg, b, e, K.rsq);
       }
     }
 #pragma unroll

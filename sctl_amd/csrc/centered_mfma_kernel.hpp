@@ -67,11 +67,6 @@ __device__ __forceinline__ u32x4 b_tail(float tt) {
 }
 
 // a.xt: Morton-sorted targets; a.v_trg / a.partial indexed like a.xt (as centered_kernel)
-#if defined(SCTL_AMD_EXPERIMENTS) && defined(SCTL_AMD_EXP_MFMA_WAVES)   // A/B builds: waves per SIMD asked of the compiler
-#define SCTL_AMD_MFMA_ATTR __attribute__((amdgpu_waves_per_eu(SCTL_AMD_EXP_MFMA_WAVES, SCTL_AMD_EXP_MFMA_WAVES)))
-#else
-#define SCTL_AMD_MFMA_ATTR
-#endif
 // CB: column blocks of 32 targets per wave (4: 128 targets, as the VALU kernel with two targets per lane; 8: 256).  STEP: keep ONE column block's MFMAs
 // ahead of the VALU work, no more (two sets of results in registers instead of one per block)
 template <bool DL, int CB, bool STEP> __device__ __forceinline__ void centered_mfma_f32_body(const EvalArgs<float>& a) {
@@ -159,7 +154,7 @@ template <bool DL, int CB, bool STEP> __device__ __forceinline__ void centered_m
   if (ntile > 0) load_source(0);
 
   // ---- near sources: the reference-exact masked pair, in batches (as centered_kernel) ------------------------------------
-  const R far_off = R(1.0e3) * (R(1) + sqrt_(rt2));
+  const R far_off = uniform_(R(1.0e3) * (R(1) + sqrt_(rt2)));
   auto put_near = [&](int q, const R (&xq)[3], const R (&nq)[3], const R (&fq)[1]) {
     R rec[4 * NEARW] = {};
     pack_record<Ker, R, 0>(rec, xq, nq, fq);
@@ -169,16 +164,23 @@ template <bool DL, int CB, bool STEP> __device__ __forceinline__ void centered_m
   int nn = 0;
   auto flush_near = [&]() {
     if (nn & 1) {
-      if (lane == 0) {   // null source: zero density far away
-        const R xq[3] = {c[0] + far_off, c[1], c[2]}, nq[3] = {0, 0, 0}, fq[1] = {0};
+      if (lane == 0) {   // null source: zero density far away (built here from scalars, not kept in four registers for the whole kernel)
+        R cx = c[0], fo = far_off;
+        asm volatile("" : "+v"(cx), "+v"(fo));
+        const R xq[3] = {cx + fo, c[1], c[2]}, nq[3] = {0, 0, 0}, fq[1] = {0};
         put_near(nn, xq, nq, fq);
       }
       __syncthreads();
     }
     R xo[NQ][3];
+    // (the targets' addresses are recomputed HERE, from values the optimiser cannot see through: hoisted out of the tile loop — this path runs once per
+    // few hundred tiles — they cost the 256-target kernel eight registers it does not have, i.e. 68 bytes of scratch per lane and 9 GB of scratch stores per 2^23 launch)
+    int lo = lane;
+    asm volatile("" : "+v"(lo));
+    const int mo = lo & 31, ho = lo >> 5;
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
-      int64_t t = tbase + (NQ * h + q) * 32 + m;
+      int64_t t = tbase + (NQ * ho + q) * 32 + mo;
       if (t >= a.Nt) t = a.Nt - 1;
 #pragma unroll
       for (int k = 0; k < 3; k++) xo[q][k] = a.xt[t * 3 + k];
@@ -250,8 +252,11 @@ template <bool DL, int CB, bool STEP> __device__ __forceinline__ void centered_m
 #pragma unroll
     for (int cb = 0; cb < kColBlocks; cb++) tacc[cb] = f32x2{0, 0};
     const f32x16 zero = {};
+    int lr = lane;   // (this lane's row and half, made per call: see the epilogue)
+    asm volatile("" : "+v"(lr));
+    const u32x4* const row0 = farA + (lr & 31) * RW + (lr >> 5);
     for (int r0 = 0; r0 < nrows; r0 += kMfmaRows) {
-      const u32x4* row = farA + (r0 + m) * RW + h;
+      const u32x4* row = row0 + r0 * RW;
       const u32x4 A0 = row[0], A1 = row[2];
       if constexpr (DL) {
         const u32x4 G0 = row[4], G1 = row[6];
@@ -265,27 +270,10 @@ template <bool DL, int CB, bool STEP> __device__ __forceinline__ void centered_m
           }
           // in batches — 16 reciprocal square roots, their cubes, the accumulation — so that no instruction waits for the one before it
           // (left to itself the compiler emitted rsq, rsq, mul, mul, fma as ONE dependent chain per register pair: 30 cycles per wave-pair)
-#ifndef SCTL_AMD_EXP_DL_BATCH
-#define SCTL_AMD_EXP_DL_BATCH 2
-#endif
-#if SCTL_AMD_EXP_DL_BATCH == 0   // (A/B builds) the plain loop
-#pragma unroll
-          for (int v = 0; v < 16; v += 2) {
-            const f32x2 y = {__builtin_amdgcn_rsqf(r2[v]), __builtin_amdgcn_rsqf(r2[v + 1])};
-            tacc[cb] += f32x2{rn[v], rn[v + 1]} * (y * y * y);
-          }
-#else
+          // (the plain loop, and cubes per pair of values: profiles/r03_ab_mfma_variants.txt)
 #pragma unroll
           for (int v = 0; v < 16; v++) r2[v] = __builtin_amdgcn_rsqf(r2[v]);
           __builtin_amdgcn_sched_barrier(0);
-#if SCTL_AMD_EXP_DL_BATCH == 1   // (A/B builds) cube per pair of values: 168 registers = three waves per SIMD, but y^2 -> y^3 back to back
-#pragma unroll
-          for (int v = 0; v < 16; v += 2) {
-            const f32x2 y = {r2[v], r2[v + 1]}, y3 = y * y * y;
-            r2[v] = y3[0]; r2[v + 1] = y3[1];
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#else
 #pragma unroll
           for (int v0 = 0; v0 < 16; v0 += 8) {   // (eight values at a time: a full set of squares costs 16 more registers)
             f32x2 q[4];
@@ -299,7 +287,6 @@ template <bool DL, int CB, bool STEP> __device__ __forceinline__ void centered_m
             }
             __builtin_amdgcn_sched_barrier(0);
           }
-#endif
           f32x2 t2 = {0, 0};   // a second chain: consecutive FMAs into one accumulator wait for each other
 #pragma unroll
           for (int v = 0; v < 16; v += 4) {
@@ -308,14 +295,13 @@ template <bool DL, int CB, bool STEP> __device__ __forceinline__ void centered_m
           }
           tacc[cb] += t2;
           __builtin_amdgcn_sched_barrier(0);
-#endif
           r2 = r2n; rn = rnn;
         }
         asm volatile("" ::"v"(A0), "v"(A1), "v"(G0), "v"(G1));   // operands stay untouched until the VALU work behind the last MFMA is done (see the end of the kernel)
       } else {
         f32x4 fr[4];   // densities of this lane's rows 8 k + 4 h + {0..3}
 #pragma unroll
-        for (int k = 0; k < 4; k++) fr[k] = farF4[(r0 >> 2) + 2 * k + h];
+        for (int k = 0; k < 4; k++) fr[k] = farF4[(r0 >> 2) + 2 * k + (lr >> 5)];
         f32x16 r2 = mfma(A1, Bop[0][1], mfma(A0, Bop[0][0], zero));
 #pragma unroll
         for (int cb = 0; cb < kColBlocks; cb++) {
@@ -380,12 +366,16 @@ template <bool DL, int CB, bool STEP> __device__ __forceinline__ void centered_m
   for (int cb = 0; cb < kColBlocks; cb++) asm volatile("" ::"v"(Bop[cb][0]), "v"(Bop[cb][1]));
 
   // the two half-waves hold sums over different source rows of the same targets
+  // (lane-derived values of this epilogue are made here, not carried through the tile loop in registers the 256-target kernel would have to spill)
+  int le = lane;
+  asm volatile("" : "+v"(le));
+  const int me = le & 31, he = le >> 5, partner = (le ^ 32) << 2;
 #pragma unroll
-  for (int cb = 0; cb < kColBlocks; cb++) acc[cb] += __shfl_xor(acc[cb], 32);
+  for (int cb = 0; cb < kColBlocks; cb++) acc[cb] += __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(acc[cb])));
 #pragma unroll
   for (int q = 0; q < NQ; q++) {
-    const int64_t t = tbase + (NQ * h + q) * 32 + m;
-    const R sum = (h ? acc[NQ + q] : acc[q]) + accn[q][0];
+    const int64_t t = tbase + (NQ * he + q) * 32 + me;
+    const R sum = (he ? acc[NQ + q] : acc[q]) + accn[q][0];
     if (t < a.Nt) {
       if (gridDim.y == 1) a.v_trg[t] += sum * a.scale;
       else a.partial[(int64_t)split_idx * a.Nt + t] = sum;
@@ -397,11 +387,13 @@ template <bool DL, int CB, bool STEP> __device__ __forceinline__ void centered_m
 // itself it issues all eight blocks' first MFMAs up front, 186 registers, two waves) — 426 against 446 ms at 2^21 for the 128-target form, which loses 3 % under
 // the same fence and gains nothing from a fourth wave (profiles/r03_ab_mfma_sl_occupancy.txt).  Double layer: 256 targets per wave, two waves per SIMD
 // (centered.hip: centered_targets_per_wave).  The 128-target forms stay for A/B runs (SCTL_AMD_MFMA_CB=4).
-template <bool DL, int CB> __global__ void __launch_bounds__(kWaveBlock) SCTL_AMD_MFMA_ATTR centered_mfma_f32_kernel(const EvalArgs<float> a) {
+template <bool DL, int CB> __global__ void __launch_bounds__(kWaveBlock) centered_mfma_f32_kernel(const EvalArgs<float> a) {
   centered_mfma_f32_body<DL, CB, false>(a);
 }
 __global__ void __launch_bounds__(kWaveBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) centered_mfma_fxu256_f32_kernel(const EvalArgs<float> a) {
   centered_mfma_f32_body<false, 8, true>(a);
 }
+// (192 targets per wave — six column blocks, 23 registers fewer — measured 0.8-2.4 % slower than 256 and is not kept: profiles/r04_ab_mfma_sl.txt.  Two
+// v_fma_f32 instead of one v_pk_fma_f32 in the accumulation beside the MFMAs: +0.5 %, within the noise, same record.)
 
 }  // namespace sctl_amd

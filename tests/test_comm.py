@@ -71,6 +71,12 @@ def test_comm_world_is_self_for_independent_tasks(tmp_path):
                   {"WORLD_SIZE": "2", "RANK": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port()), "SCTL_AMD_COMM": "0"}):
         r = subprocess.run([exe, "10", str(tmp_path / "x"), "hostonly"], env=dict(base, **extra), capture_output=True, text=True, timeout=60)
         assert r.returncode == 0 and "rank 0 of 1" in r.stdout, (extra, r.stdout, r.stderr)
+        # several tasks reported and no rendezvous named: each evaluates on its own sources — said once on stderr (under the reference's contract, the
+        # potential from ALL ranks' sources, that is another answer); switched off explicitly it is the user's choice and silent
+        warned = "tasks detected" in r.stderr and "NOT rank-parallel" in r.stderr
+        assert warned == ("SCTL_AMD_COMM" not in extra), (extra, r.stderr)
+        quiet = subprocess.run([exe, "10", str(tmp_path / "x"), "hostonly"], env=dict(base, SCTL_AMD_COMM_QUIET="1", **extra), capture_output=True, text=True, timeout=60)
+        assert quiet.returncode == 0 and "tasks detected" not in quiet.stderr
 
 
 def test_rendezvous_drops_stray_connections_and_keeps_listening():

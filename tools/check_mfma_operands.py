@@ -4,9 +4,7 @@ out of its matrix-core kernels (sctl_amd/csrc/centered_mfma_kernel.hpp, DESIGN.m
 issued v_mfma reads as its A or B operand.  A precaution — whether such a write can land before an MFMA that waits in the matrix pipe has read the register
 is not documented —: for every v_mfma of the matrix-core kernels the next WINDOW vector / LDS / memory instructions along both arms of every branch must not
 write the MFMA's A / B registers (its own destination included).
-It also LISTS (does not fail) vector instructions directly behind a transcendental one that overwrite the transcendental's source register: the pair
-`v_rsq_f32 vA, vB ; v_pk_mul_f32 v[B:B+1]` was the first suspect for the run-to-run different near sums of round 3 and was cleared by experiment
-(tools/kernel_repeat.sh: one s_nop between the two does not remove the fault) — kept as information for whoever meets that fault again.
+(What used to be listed here — vector instructions overwriting a transcendental's source — is tools/check_isa_rules.py's now, with what round 4 found about it.)
     python tools/check_mfma_operands.py [asm file]      exit code 1 on a finding; without a file it compiles sctl_amd/csrc/centered.hip"""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -87,24 +85,6 @@ def check(body):
     return n, found
 
 
-TRANS = ('v_rsq_', 'v_rcp_', 'v_sqrt_', 'v_exp_', 'v_log_', 'v_sin_', 'v_cos_')
-
-
-def check_trans(body):
-    """(packed followers that overwrite a transcendental's source, other such followers) as lists of (line, trans, follower)"""
-    ins = [(i, p) for i, l in enumerate(body) for p in [parse(l)] if p]
-    packed, other = [], []
-    for k, (i, (op, dst, ops)) in enumerate(ins[:-1]):
-        if not op.startswith(TRANS) or len(ops) < 2:
-            continue
-        j, (op2, dst2, ops2) = ins[k + 1]
-        if op2.startswith(TRANS) or op2.startswith('v_mfma') or not op2.startswith('v_'):
-            continue          # the transcendental unit works in order; an MFMA writes its result tens of cycles later
-        if dst2 & regs(ops[1]):
-            (packed if op2.startswith('v_pk_') else other).append((i, body[i].strip(), body[j].strip()))
-    return packed, other
-
-
 def main():
     if len(sys.argv) > 1:
         src = open(sys.argv[1]).read()
@@ -123,14 +103,6 @@ def main():
         for o, ol, i, il in found[:10]:
             print("   line %d  %s\n      <- line %d  %s" % (o, ol, i, il))
         bad += len(found)
-    for name, body in kernels(src, "sctl_amd"):
-        packed, other = check_trans(body)
-        if packed or other:
-            print("%s: transcendental source overwritten by the next instruction (listed, not a failure): %d packed, %d other" % (name, len(packed), len(other)))
-            for i, a, b in packed:
-                print("        line %d  %s ; %s   [packed]" % (i, a, b))
-            for i, a, b in other[:4]:
-                print("        line %d  %s ; %s" % (i, a, b))
     return 1 if bad else 0
 
 
