@@ -13,6 +13,11 @@
 //     while the current tile is evaluated;
 //   * the pair evaluation is the kernel's own exact pair(); a box interacts with itself, so tiles are evaluated speculatively
 //     without the r = 0 mask and repaired when a coincident pair shows up (as in eval_kernel.hpp).
+//   * SMALL target ranges (up to 64 points: the leaves of a deep tree) are PACKED (round 4): a wave takes 64 / P consecutive ranges at once, P = 8, 16 or 32
+//     lanes each with one or two targets per lane, every group of lanes walking ITS OWN source sequence — a flat list of source indices the plan
+//     makes once — P sources at a time through its slice of the LDS tile.  All 64 lanes do pair work in every step, and what a wave pays once (its
+//     work item, its targets, the latency of the first sources) is spread over eight boxes instead of one: a leaf of ~8 points went from 4.9 % to
+//     [see DESIGN.md §4.6] of the fp64 peak.
 #pragma once
 #include "eval_kernel.hpp"
 
@@ -31,6 +36,16 @@ struct ListRange {      // sources [s0, s0 + ns)
   int64_t s0;
   int64_t ns;
 };
+// A PACKED work item is a ListItem with nranges = -1 - class: t0 = its first group, nt = how many groups (<= 64 / P).  Classes (P lanes per group x T
+// targets per lane >= the group's targets):   0: 8 x 1   1: 8 x 2   2: 16 x 2   3: 32 x 2
+struct PackedGroup {    // one small target range and its sources
+  int64_t t0;           // first target
+  int64_t flat_off;     // first entry of its source sequence in the flat index list
+  int32_t nt;           // targets, 1 .. 64
+  int32_t nsrc;         // sources: all ranges listed for the target range, concatenated in list order
+};
+constexpr int kPackedLanes[4] = {8, 8, 16, 32};
+constexpr int kPackedTargets[4] = {1, 2, 2, 2};
 
 template <class R> struct ListArgs {
   int32_t xcd_first[9];   // items [xcd_first[x], xcd_first[x + 1]) are the share of XCD x (see lists_kernel)
@@ -43,6 +58,8 @@ template <class R> struct ListArgs {
   R* v_trg;         // [Nt*K1], accumulated into
   R scale;
   KerCtx ctx;
+  const PackedGroup* groups;   // packed items only
+  const uint32_t* flat;        // their source sequences: indices into xs / xn / f
 };
 
 // One work item with T targets per lane.  Each LDS tile is first evaluated WITHOUT the r = 0 mask into per-tile sums; a coincident
@@ -209,13 +226,164 @@ __device__ __forceinline__ void lists_item(const ListArgs<R>& a, const ListItem&
   }
 }
 
+// One PACKED work item: up to 64 / P small target ranges, P lanes x T targets per lane each.  Group g = lane / P walks its own source sequence P sources at a
+// time: lane i of the group fetches the (k P + i)-th source, packs it into the group's slice of the LDS tile (slices one 16-byte word apart from a multiple of
+// 32 banks: the groups' reads — one address per group — do not collide), and every lane of the group evaluates its T targets against the slice.  The next step's
+// sources are in flight meanwhile.  Sums are kept per target in list order (per-step partial sums, added in step order): deterministic.
+// A step runs without the r = 0 mask and is repaired when a coincident pair shows up, as in lists_item — except that a step KNOWN to hold coincident pairs is run
+// masked at once: when the caller's sources ARE its targets (launch-uniform: one array) a lane sees that the source it fetched is one of its group's own
+// targets.  With eight boxes per wave some group is at its own points in a third of the steps; evaluating those twice would cost more than the whole mask.
+template <class Ker, class R, int MODE, int P, int T, class KC, class V>
+__device__ __forceinline__ void lists_packed_item(const ListArgs<R>& a, const ListItem& it, V* tile, const KC& K) {
+  constexpr int K0 = Ker::K0, K1 = Ker::K1, ND = Ker::ND, NREC = Ker::NREC;
+  constexpr int VN = VecOf<R>::N;
+  constexpr int NV = (NREC + VN - 1) / VN;
+  constexpr int NRECP = NV * VN;
+  constexpr int G = kListWave / P, SLICE = P * NV + 1;      // 16-byte words per group slice (+ 1: bank spread)
+  static_assert(G * SLICE <= kListTile * NV + 8, "the packed slices fit the list kernel's LDS tile");
+  const int lane = threadIdx.x, g = lane / P, i = lane % P;
+  const bool live = g < it.nt;                              // (it.nt = groups of this item)
+  const PackedGroup pg = a.groups[it.t0 + (live ? g : 0)];
+  const int nsrc = live ? pg.nsrc : 0;
+  const bool self = (const void*)a.xs == (const void*)a.xt;
+
+  R xt[T][3], acc[T][K1];
+#pragma unroll
+  for (int j = 0; j < T; j++) {
+    int tl = j * P + i;
+    if (tl >= pg.nt) tl = pg.nt - 1;                        // idle slots repeat the last target; never stored
+    const int64_t t = pg.t0 + tl;
+#pragma unroll
+    for (int k = 0; k < 3; k++) xt[j][k] = a.xt[t * 3 + k];
+#pragma unroll
+    for (int k = 0; k < K1; k++) acc[j][k] = 0;
+  }
+  int nmax = nsrc;                                          // the longest sequence of the wave decides the trip count
+  for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(nmax, o); nmax = (w > nmax) ? w : nmax; }
+  nmax = __builtin_amdgcn_readfirstlane(nmax);
+  const int nsteps = (nmax + P - 1) / P;
+
+  R sx[3] = {0, 0, 0}, sn[3] = {0, 0, 0}, sf[K0];
+#pragma unroll
+  for (int k = 0; k < K0; k++) sf[k] = 0;
+  // The sources of a step are fetched one step ahead, their INDICES two steps ahead: index -> coordinates is a chain of two memory latencies, and a step of
+  // eight sources is short.  idx_next: this lane's source of the step after the one being gathered (-1: none).
+  bool own = false;    // the source this lane holds for the coming step is one of its group's targets
+  auto load_idx = [&](int step) -> int64_t {
+    const int q = step * P + i;
+    return (q < nsrc) ? (int64_t)a.flat[pg.flat_off + q] : (int64_t)-1;
+  };
+  int64_t idx_next = (nsteps > 0) ? load_idx(0) : (int64_t)-1;
+  auto fetch = [&](int step) {
+    const int64_t src = idx_next;
+    idx_next = (step + 1 < nsteps) ? load_idx(step + 1) : (int64_t)-1;
+    own = false;
+    if (src >= 0) {
+      own = self && src >= pg.t0 && src < pg.t0 + pg.nt;
+#pragma unroll
+      for (int k = 0; k < 3; k++) sx[k] = a.xs[src * 3 + k];
+#pragma unroll
+      for (int k = 0; k < ND; k++) sn[k] = a.xn[src * ND + k];
+#pragma unroll
+      for (int k = 0; k < K0; k++) sf[k] = a.f[src * K0 + k];
+    }
+  };
+  V* const slice = tile + g * SLICE;
+  if (nsteps > 0) fetch(0);
+  for (int step = 0; step < nsteps; step++) {
+    __syncthreads();   // previous slices fully consumed
+    const int cnt = nsrc - step * P;                        // sources of this group in this step: >= P (full), 1 .. P - 1 (its last), <= 0 (done)
+    const bool known_coincident = __any(own);               // (of the step being staged now: `own` belongs to the sources fetched for it)
+    if (i < cnt) {
+      R rec[NRECP] = {};
+      pack_record<Ker, R, MODE>(rec, sx, sn, sf);
+#pragma unroll
+      for (int v = 0; v < NV; v++) {
+        V w;
+#pragma unroll
+        for (int e = 0; e < VN; e++) w[e] = rec[v * VN + e];
+        slice[i * NV + v] = w;
+      }
+    }
+    if (step + 1 < nsteps) fetch(step + 1);
+    __syncthreads();
+
+    R tacc[T][K1];
+    const bool full = __all(cnt >= P);                      // wave-uniform: every group has a whole slice (all steps but the groups' last ones)
+    auto run_step_v = [&](auto masked_tag, auto variant_tag) {
+      constexpr bool MASKED = decltype(masked_tag)::value;
+      constexpr int VARIANT = decltype(variant_tag)::value;
+      K.begin_tile();
+#pragma unroll
+      for (int j = 0; j < T; j++)
+#pragma unroll
+        for (int k = 0; k < K1; k++) tacc[j][k] = 0;
+      auto one_source = [&](int s) {
+        R rec[NRECP];
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+          const V w = slice[s * NV + v];
+#pragma unroll
+          for (int e = 0; e < VN; e++) rec[v * VN + e] = w[e];
+        }
+#pragma unroll
+        for (int j = 0; j < T; j++) {
+          const R d[3] = {xt[j][0] - rec[0], xt[j][1] - rec[1], xt[j][2] - rec[2]};
+          if constexpr (KC::HAS_VARIANT) Ker::template pair<R, MODE, MASKED, VARIANT>(tacc[j], d, rec, a.ctx, K);
+          else Ker::template pair<R, MODE, MASKED>(tacc[j], d, rec, a.ctx, K);
+        }
+      };
+      if (full) {
+#pragma unroll UnrollOf<T, Ker::K1>::value
+        for (int s = 0; s < P; s++) one_source(s);
+      } else {
+        for (int s = 0; s < P; s++)
+          if (s < cnt) one_source(s);
+      }
+    };
+    auto run_step = [&](auto masked_tag) {
+      if constexpr (KC::HAS_VARIANT) {
+        if (K.variant(a.ctx) & 1) run_step_v(masked_tag, std::integral_constant<int, 1>());
+        else run_step_v(masked_tag, std::integral_constant<int, 0>());
+      } else {
+        run_step_v(masked_tag, std::integral_constant<int, 0>());
+      }
+    };
+    bool repaired = true;
+    if (!known_coincident) {
+      run_step(std::false_type());
+      bool bad = K.tile_bad(a.ctx);
+#pragma unroll
+      for (int j = 0; j < T; j++)
+#pragma unroll
+        for (int k = 0; k < K1; k++) bad |= !(fabs_(tacc[j][k]) <= max_finite<R>());
+      repaired = __any(bad);
+    }
+    if (repaired) run_step(std::true_type());
+#pragma unroll
+    for (int j = 0; j < T; j++)
+#pragma unroll
+      for (int k = 0; k < K1; k++) acc[j][k] += tacc[j][k];
+  }
+#pragma unroll
+  for (int j = 0; j < T; j++) {
+    const int tl = j * P + i;
+    finish_acc<Ker, R, MODE>(acc[j]);
+    if (live && tl < pg.nt) {
+      const int64_t t = pg.t0 + tl;
+#pragma unroll
+      for (int k = 0; k < K1; k++) a.v_trg[t * K1 + k] += acc[j][k] * a.scale;   // generic-kernel.txx:184
+    }
+  }
+}
+
 // An item with more than 64 targets runs two targets per lane (half the LDS reads per pair), one with 33..64 a single target per
 // lane (no idle second slot), a smaller one replicas of 8..32 lanes (lists_item, SPLIT); lists.hip cuts the target ranges accordingly.
 template <class Ker, class R, int MODE>
 __global__ void __launch_bounds__(kListWave) lists_kernel(const ListArgs<R> a) {
   using V = typename VecOf<R>::type;
   constexpr int NV = (Ker::NREC + VecOf<R>::N - 1) / VecOf<R>::N;
-  __shared__ V tile[kListTile * NV];
+  __shared__ V tile[kListTile * NV + 8];     // (+ 8: the packed items' slices are one word apart)
   using KC = typename Ker::template Consts<R>;
   __shared__ double kscratch[KC::LDS_DOUBLES > 0 ? KC::LDS_DOUBLES : 1];
   const KC K = make_consts<KC>(kscratch, a.ctx, MODE);
@@ -227,6 +395,14 @@ __global__ void __launch_bounds__(kListWave) lists_kernel(const ListArgs<R> a) {
   const int xcd = blockIdx.x % 8, j = blockIdx.x / 8;
   if (j >= a.xcd_first[xcd + 1] - a.xcd_first[xcd]) return;
   const ListItem it = a.items[a.xcd_first[xcd] + j];
+  if (it.nranges < 0) {      // packed small target ranges
+    const int cls = -1 - it.nranges;
+    if (cls == 0) lists_packed_item<Ker, R, MODE, 8, 1>(a, it, tile, K);
+    else if (cls == 1) lists_packed_item<Ker, R, MODE, 8, 2>(a, it, tile, K);
+    else if (cls == 2) lists_packed_item<Ker, R, MODE, 16, 2>(a, it, tile, K);
+    else lists_packed_item<Ker, R, MODE, 32, 2>(a, it, tile, K);
+    return;
+  }
   if (it.nt > kListWave) lists_item<Ker, R, MODE, 2, false>(a, it, tile, K);
   else if (it.nt > kListWave / 2) lists_item<Ker, R, MODE, 1, false>(a, it, tile, K);
   else lists_item<Ker, R, MODE, 1, true>(a, it, tile, K);

@@ -5,6 +5,7 @@
 #include "workspace.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -25,7 +26,8 @@ struct sctl_amd_lists {
   int real = 0, device = 0;
   int64_t Nt = 0, Ns = 0, nitems = 0, nranges = 0, pairs = 0, nblocks = 0;
   int32_t xcd_first[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  void *d_items = nullptr, *d_ranges = nullptr;
+  void *d_items = nullptr, *d_ranges = nullptr, *d_groups = nullptr, *d_flat = nullptr;   // (groups + flat source indices: the packed small target ranges)
+  int64_t npacked_groups = 0, nflat = 0;
   // host-pointer evaluation: device copies of the caller's arrays and pinned staging, grown on demand
   hipStream_t st = nullptr;
   void* dbuf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -35,6 +37,11 @@ struct sctl_amd_lists {
 };
 
 using namespace sctl_amd;
+// Target ranges of up to this many points are packed, several to a wave (lists_kernel.hpp); larger ones keep a wave (or several) to themselves.  Measured on
+// 2^21 points in g^3 boxes, every box against its 27 neighbours (tools/time_lists.py, profiles/r04_time_lists_classes.txt; Laplace / Stokeslet, % of the fp64
+// peak, packing up to 0 | 8 | 16 | 32 | 64 points): ~8 per box 4.4 | 6.6 | 11.2 | 11.3 | 11.0 and 11.7 | 15.8 | 23.7 | 23.9 | 23.6; ~11 per box 7.3 | 7.7 | 11.5 |
+// 12.9 | 12.8; ~24 per box 12.0 | 11.9 | 11.8 | 15.5 | 15.5; ~64 per box 21.1 | 20.9 | 20.9 | 20.7 | 18.3 and 45.7 | 46.5 | 46.0 | 46.0 | 40.6: 32.
+constexpr int64_t kPackUpTo = 32;
 
 extern "C" {
 
@@ -81,6 +88,21 @@ int sctl_amd_lists_create(int kernel, int real, int device, int64_t nlists, cons
   // pair count.  Inside a share: long items first (a short tail), coarsely — by the number of 4096-source chunks —, neighbours
   // otherwise staying neighbours.
   std::vector<ListItem> items;
+  std::vector<PackedGroup> pgroups;
+  std::vector<uint32_t> flat;
+  // The packed form keeps one 32-bit source index per (small target range, source): it is used while that list stays below 2^30 entries (4 GB) and the
+  // sources can be indexed with 32 bits; SCTL_AMD_LISTS_PACK=0 keeps every range on the one-range-per-wave items (A/B runs, tests of that path)
+  bool pack_small = Ns <= (int64_t)UINT32_MAX;
+  int64_t pack_upto = kPackUpTo;
+  if (const char* e = std::getenv("SCTL_AMD_LISTS_PACK")) pack_upto = std::min<int64_t>(64, std::atoi(e));   // (0: off; 8 / 16 / 32 / 64: the largest packed range)
+  pack_small = pack_small && pack_upto > 0;
+  if (pack_small) {
+    int64_t entries = 0;
+    for (const Group& g : groups)
+      if (g.nt <= pack_upto) entries += g.nsrc;
+    if (entries > ((int64_t)1 << 30)) pack_small = false;
+    else flat.reserve((size_t)entries);
+  }
   int32_t xcd_first[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   {
     size_t g0 = 0;
@@ -92,8 +114,15 @@ int sctl_amd_lists_create(int kernel, int real, int device, int64_t nlists, cons
       std::vector<size_t> gorder(g1 - g0);
       std::iota(gorder.begin(), gorder.end(), g0);
       std::stable_sort(gorder.begin(), gorder.end(), [&](size_t a, size_t b) { return (groups[a].nsrc >> 12) > (groups[b].nsrc >> 12); });
+      // Small target ranges (<= 64 points) are PACKED (lists_kernel.hpp): those of one class (lanes x targets per lane) share waves, 64 / P at a time, in
+      // the share's order — neighbours along the caller's space-filling curve —, each with its flat source sequence.  They follow the share's larger items.
+      std::vector<size_t> small[4];
       for (size_t gi : gorder) {
         const Group& g = groups[gi];
+        if (pack_small && g.nt <= pack_upto && g.nsrc <= INT32_MAX) {
+          small[g.nt <= 8 ? 0 : g.nt <= 16 ? 1 : g.nt <= 32 ? 2 : 3].push_back(gi);
+          continue;
+        }
         // 128-target items (two targets per lane: half the LDS reads per pair); the remainder: more than 96 -> one more such item,
         // 65..96 -> a one-target-per-lane item of 64 plus a small one, up to 64 -> one item (up to 32: run as lane replicas)
         for (int64_t t = 0; t < g.nt;) {
@@ -101,6 +130,17 @@ int sctl_amd_lists_create(int kernel, int real, int device, int64_t nlists, cons
           const int64_t n = left > 96 ? std::min<int64_t>(left, 2 * kListWave) : (left > kListWave ? kListWave : left);
           items.push_back(ListItem{g.t0 + t, (int32_t)n, (int32_t)g.nranges, g.first_range});
           t += n;
+        }
+      }
+      for (int cls = 3; cls >= 0; cls--) {
+        const size_t per_item = (size_t)(kListWave / kPackedLanes[cls]);
+        for (size_t k = 0; k < small[cls].size(); k++) {
+          if (k % per_item == 0) items.push_back(ListItem{(int64_t)pgroups.size(), 0, -1 - cls, 0});
+          const Group& g = groups[small[cls][k]];
+          items.back().nt++;
+          pgroups.push_back(PackedGroup{g.t0, (int64_t)flat.size(), (int32_t)g.nt, (int32_t)g.nsrc});
+          for (int64_t r = g.first_range; r < g.first_range + g.nranges; r++)
+            for (int64_t q = 0; q < ranges[(size_t)r].ns; q++) flat.push_back((uint32_t)(ranges[(size_t)r].s0 + q));
         }
       }
       if (items.size() > 0x7ffffff0u) return set_error(SCTL_AMD_ERR_BAD_ARGUMENT, "too many work items for one launch");
@@ -115,6 +155,7 @@ int sctl_amd_lists_create(int kernel, int real, int device, int64_t nlists, cons
   sctl_amd_lists* p = new sctl_amd_lists;
   p->k = k; p->real = real; p->device = device; p->Nt = Nt; p->Ns = Ns;
   p->nitems = (int64_t)items.size(); p->nranges = (int64_t)ranges.size(); p->pairs = pairs; p->nblocks = longest * 8;
+  p->npacked_groups = (int64_t)pgroups.size(); p->nflat = (int64_t)flat.size();
   std::memcpy(p->xcd_first, xcd_first, sizeof xcd_first);
   *out = p;
   if (items.empty()) return SCTL_AMD_OK;       // nothing to do: legal, and needs no device
@@ -134,16 +175,22 @@ int sctl_amd_lists_create(int kernel, int real, int device, int64_t nlists, cons
   // the vectors are fresh, written once and alive until the synchronous copies return
   if ((e = hipMemcpy(p->d_items, items.data(), items.size() * sizeof(ListItem), hipMemcpyHostToDevice)) != hipSuccess) return fail_hip(e, "hipMemcpy(items)");
   if ((e = hipMemcpy(p->d_ranges, ranges.data(), ranges.size() * sizeof(ListRange), hipMemcpyHostToDevice)) != hipSuccess) return fail_hip(e, "hipMemcpy(ranges)");
+  if (!pgroups.empty()) {
+    if ((e = hipMalloc(&p->d_groups, pgroups.size() * sizeof(PackedGroup))) != hipSuccess) return fail_hip(e, "hipMalloc(groups)");
+    if ((e = hipMalloc(&p->d_flat, flat.size() * sizeof(uint32_t))) != hipSuccess) return fail_hip(e, "hipMalloc(flat)");
+    if ((e = hipMemcpy(p->d_groups, pgroups.data(), pgroups.size() * sizeof(PackedGroup), hipMemcpyHostToDevice)) != hipSuccess) return fail_hip(e, "hipMemcpy(groups)");
+    if ((e = hipMemcpy(p->d_flat, flat.data(), flat.size() * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess) return fail_hip(e, "hipMemcpy(flat)");
+  }
   return SCTL_AMD_OK;
 }
 
 void sctl_amd_lists_destroy(sctl_amd_lists* p) {
   if (!p) return;
-  if (p->d_items || p->d_ranges || p->st || p->pinned) {
+  if (p->d_items || p->d_ranges || p->d_groups || p->d_flat || p->st || p->pinned) {
     DeviceScope scope(p->device);
     if (scope.err == hipSuccess) {
       if (p->st) (void)hipStreamSynchronize(p->st);
-      for (void* b : {p->d_items, p->d_ranges, p->dbuf[0], p->dbuf[1], p->dbuf[2], p->dbuf[3], p->dbuf[4]})
+      for (void* b : {p->d_items, p->d_ranges, p->d_groups, p->d_flat, p->dbuf[0], p->dbuf[1], p->dbuf[2], p->dbuf[3], p->dbuf[4]})
         if (b) (void)hipFree(b);
       if (p->pinned) (void)hipHostFree(p->pinned);
       if (p->st) (void)hipStreamDestroy(p->st);
@@ -175,12 +222,12 @@ int sctl_amd_lists_eval_device(sctl_amd_lists* p, const void* r_trg, const void*
   const double scale = k.scale / k.acc_factor[mode];
   if (p->real == SCTL_AMD_F64) {
     ListArgs<double> a{{0}, (const ListItem*)p->d_items, (const ListRange*)p->d_ranges, (const double*)r_trg, (const double*)r_src, (const double*)n_src,
-                       (const double*)v_src, (double*)v_trg, scale, make_ctx(k, ctx)};
+                       (const double*)v_src, (double*)v_trg, scale, make_ctx(k, ctx), (const PackedGroup*)p->d_groups, (const uint32_t*)p->d_flat};
     std::memcpy(a.xcd_first, p->xcd_first, sizeof a.xcd_first);
     k.lists_f64[mode](a, p->nblocks, (hipStream_t)stream);
   } else {
     ListArgs<float> a{{0}, (const ListItem*)p->d_items, (const ListRange*)p->d_ranges, (const float*)r_trg, (const float*)r_src, (const float*)n_src,
-                      (const float*)v_src, (float*)v_trg, (float)scale, make_ctx(k, ctx)};
+                      (const float*)v_src, (float*)v_trg, (float)scale, make_ctx(k, ctx), (const PackedGroup*)p->d_groups, (const uint32_t*)p->d_flat};
     std::memcpy(a.xcd_first, p->xcd_first, sizeof a.xcd_first);
     k.lists_f32[mode](a, p->nblocks, (hipStream_t)stream);
   }
@@ -217,15 +264,17 @@ int sctl_amd_lists_eval_host(sctl_amd_lists* p, const void* r_trg, const void* r
     LISTS_TRY(hipHostMalloc((void**)&p->pinned, total, hipHostMallocPortable));
     p->pinned_cap = total;
   }
+  // the caller's sources ARE its targets (one array): one device copy, which is how the kernel knows that every box meets its own points
+  const bool same = r_src == r_trg && bytes[0] == bytes[1];
   Carver cut(p->pinned);
   for (int i = 0; i < 4; i++) {
     char* q = cut.take<char>(bytes[i]);
-    if (!bytes[i]) continue;
+    if (!bytes[i] || (i == 1 && same)) continue;
     std::memcpy(q, src[i], bytes[i]);
     LISTS_TRY(hipMemcpyAsync(p->dbuf[i], q, bytes[i], hipMemcpyHostToDevice, p->st));
   }
   LISTS_TRY(hipMemsetAsync(p->dbuf[4], 0, bytes[4], p->st));
-  const int rc = sctl_amd_lists_eval_device(p, p->dbuf[0], p->dbuf[1], p->dbuf[2], p->dbuf[3], p->dbuf[4], digits, ctx, ctx_bytes, p->st);
+  const int rc = sctl_amd_lists_eval_device(p, p->dbuf[0], same ? p->dbuf[0] : p->dbuf[1], p->dbuf[2], p->dbuf[3], p->dbuf[4], digits, ctx, ctx_bytes, p->st);
   if (rc != SCTL_AMD_OK) return rc;
   char* back = cut.take<char>(bytes[4]);
   LISTS_TRY(hipMemcpyAsync(back, p->dbuf[4], bytes[4], hipMemcpyDeviceToHost, p->st));

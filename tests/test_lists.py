@@ -19,6 +19,22 @@ IDS = ["%s-%s" % (c["kernel"], c["key"]) for c in CASES]
 _NPZ = None
 
 
+@pytest.fixture(params=["packed", "packed up to 64", "one range per wave"])
+def small_ranges(request):
+    """Target ranges of up to 32 points run PACKED, several per wave, with a flat source index list (the default; SCTL_AMD_LISTS_PACK=64 also packs those of
+    33 .. 64 points, two per wave), or — SCTL_AMD_LISTS_PACK=0, and by itself when that list would pass 4 GB or the sources 2^32 — one range per wave as lane
+    replicas; every form stays tested."""
+    if request.param == "packed":
+        os.environ.pop("SCTL_AMD_LISTS_PACK", None)
+        yield True
+    else:
+        os.environ["SCTL_AMD_LISTS_PACK"] = "64" if request.param.endswith("64") else "0"
+        try:
+            yield request.param.endswith("64")
+        finally:
+            del os.environ["SCTL_AMD_LISTS_PACK"]
+
+
 def gold(case):
     global _NPZ
     if _NPZ is None:
@@ -105,14 +121,15 @@ def test_plan_argument_checks_need_no_device():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", CASES, ids=IDS)
-def test_hip_lists_match_reference_and_oracle(O, case):
+def test_hip_lists_match_reference_and_oracle(O, case, small_ranges):
     import torch
     name = case["kernel"]
     info = sctl_amd.kernel_info(name)
     lists, xt, xs, xn, f, ctx = case_data(case, info)
     dt = xt.dtype
     plan = sctl_amd.ListsPlan(name, dt, *lists, case["Nt"], case["Ns"], ctx=ctx)
-    assert plan.pairs == case["pairs"] and plan.source_ranges == case["nlists"] and plan.work_items >= case["grid"] ** 3
+    assert plan.pairs == case["pairs"] and plan.source_ranges == case["nlists"]
+    assert plan.work_items >= (case["grid"] ** 3 // 8 if small_ranges else case["grid"] ** 3)      # packed: up to eight small boxes per wave
     u = plan.eval_host(xt, xs, xn, f, digits=case["digits"])
     assert np.all(np.isfinite(u))
     assert rel_l2(u, gold(case)) <= tol(case), rel_l2(u, gold(case))                       # vs the reference
@@ -132,7 +149,7 @@ def test_hip_lists_match_reference_and_oracle(O, case):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(6))
-def test_hip_lists_random_ragged(O, seed):
+def test_hip_lists_random_ragged(O, seed, small_ranges):
     """Not a grid: target ranges of random lengths (1 .. 700, some empty), each with a random number (0 .. 40) of source ranges of random
     lengths (0 .. 300, overlapping freely, many of 1-3 points so that LDS tiles span several ranges), random kernel and precision."""
     rng = np.random.default_rng(4000 + seed)
@@ -169,20 +186,21 @@ def test_hip_lists_random_ragged(O, seed):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sctl_amd.KERNEL_NAMES)
-def test_hip_lists_every_kernel_every_item_shape(O, name):
-    """Every kernel through the three shapes of a work item — two targets per lane (200 targets), one per lane (50) and lane replicas
-    (5 and 20 targets) — with a box acting on itself; the traction kernel's mirrored output (ukernels.hpp: finish) is checked entry by entry."""
+def test_hip_lists_every_kernel_every_item_shape(O, name, small_ranges):
+    """Every kernel through every shape of a work item — two targets per lane (200 targets), and for the small ranges (50, 5, 20, 12, 33, 64, 1 targets) the four
+    packed classes or, unpacked, one target per lane and lane replicas — with a box acting on itself; the traction kernel's mirrored output (ukernels.hpp:
+    finish) is checked entry by entry."""
     rng = np.random.default_rng(77)
     info = sctl_amd.kernel_info(name)
-    tlen = np.array([200, 50, 5, 20], dtype=np.int64)
+    tlen = np.array([200, 50, 5, 20, 12, 33, 64, 1], dtype=np.int64)
     tstart = np.concatenate([[0], np.cumsum(tlen)[:-1]])
     Nt, Ns = int(tlen.sum()), 700
     xt = rng.random(Nt * 3)
     xs = np.concatenate([xt, rng.random((Ns - Nt) * 3)])      # the first Nt sources ARE the targets (r = 0 pairs in the "self" lists)
     xn, f = rng.random(Ns * info["nd"]) - 0.5, rng.random(Ns * info["k0"]) - 0.5
     to, tc, so, sc = [], [], [], []
-    for b in range(4):
-        for s0, n in ((int(tstart[b]), int(tlen[b])), (300, 173), (473, 64), (650, 3)):   # itself, then three other ranges
+    for b in range(tlen.size):
+        for s0, n in ((int(tstart[b]), int(tlen[b])), (300, 173), (473, 64), (650, 3))[:4 if b % 3 else 3]:   # itself, then two or three other ranges
             to.append(tstart[b]); tc.append(tlen[b]); so.append(s0); sc.append(n)
     lists = [np.array(a, dtype=np.int64) for a in (to, tc, so, sc)]
     ctx = np.array([3.0, 0.2]) if name.startswith("Helmholtz") else None
