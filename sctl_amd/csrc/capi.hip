@@ -218,13 +218,17 @@ namespace {
 // Tile-centred fast path (centered_kernel.hpp): Laplace single layer (fp64 and fp32) on problems large enough to amortise the
 // Morton sort of the targets.  SCTL_AMD_CENTERED=0 in the environment forces the exact kernel (used for A/B checks).
 // nt_whole: size of the target set the Nt targets were cut from as a spatially compact slab (= Nt for a whole set).
-bool has_centered_path(const KernelEntry& k) { return k.id == SCTL_AMD_LAPLACE3D_FXU || k.id == SCTL_AMD_LAPLACE3D_DXU; }
+// Laplace single and double layer (fp64 and fp32) and, fp64 only, the gradient of the single layer (round 4: far sources summed as moments)
+bool has_centered_path(const KernelEntry& k, int real) {
+  if (k.id == SCTL_AMD_LAPLACE3D_FXU || k.id == SCTL_AMD_LAPLACE3D_DXU) return true;
+  return real == SCTL_AMD_F64 && k.id == SCTL_AMD_LAPLACE3D_FXDU;
+}
 constexpr int64_t kPresortMinTargets = 1 << 17;   // sctl_amd_op_* keeps the targets of such kernels in Morton order from this size on
 
 bool use_centered(const KernelEntry& k, int real, int64_t Nt, int64_t Ns, int64_t nt_whole = 0, bool presorted = false) {
   const char* e = std::getenv("SCTL_AMD_CENTERED");   // read per call so that a test can A/B both paths in one process
   const bool enabled = !(e && e[0] == '0'), forced = (e && e[0] == '1');
-  if (!enabled || !has_centered_path(k) || Nt >= (int64_t(1) << 32)) return false;
+  if (!enabled || !has_centered_path(k, real) || Nt >= (int64_t(1) << 32)) return false;
   if (forced) return Nt >= 128 && Ns >= 64;
   // (targets already in Morton order — `presorted`, no per-call sort/gather/scatter — do not move the crossover: at 2^17 x 2^17 the
   // centred kernel itself is level with the exact one, 8.14 vs 8.05 ms, because ~10 % of the sources are near; tools/presorted_threshold.py)
@@ -883,7 +887,7 @@ int sctl_amd_op_set_targets(sctl_amd_op* op, int64_t Nt, const void* r_trg) {
   // order once, here), so that slabs are compact and an evaluation needs no sort of its own
   std::vector<char> sorted;
   op->perm.clear();
-  if ((G > 1 || (has_centered_path(*op->k) && Nt >= kPresortMinTargets)) && Nt > 0) {
+  if ((G > 1 || (has_centered_path(*op->k, op->real) && Nt >= kPresortMinTargets)) && Nt > 0) {
     // The order is computed on the FIRST device (upload all targets, bbox -> keys -> radix sort -> gather, download order and sorted
     // coordinates): ~10 ms at 2^20 points, where the host sort this replaces (round 3) took 70-90 ms on one core — more than a GPU's whole
     // share of a 2^20 x 2^20 evaluation on an 8-GPU node, and paid per call by the host-buffer entry over a device list.
@@ -1278,7 +1282,7 @@ int sctl_amd_eval_plan(int kernel, int real, int64_t Nt, int64_t Ns, int64_t Nt_
     if (trg_per_lane) *trg_per_lane = (int)(per_wave / 64);
     if (src_splits) *src_splits = splits;
     if (workgroups) *workgroups = ((Nt + per_wave - 1) / per_wave) * splits;   // one wave64 per workgroup
-    if (workspace_bytes) *workspace_bytes = (splits > 1) ? (int64_t)splits * Nt * (real == SCTL_AMD_F64 ? 8 : 4) : 0;
+    if (workspace_bytes) *workspace_bytes = (splits > 1) ? (int64_t)splits * Nt * k->k1 * (real == SCTL_AMD_F64 ? 8 : 4) : 0;
     return SCTL_AMD_OK;
   }
   const Plan p = make_plan(*k, real, Nt, Ns);

@@ -18,13 +18,11 @@ namespace sctl_amd {
     if (e_ != hipSuccess) return e_;  \
   } while (0)
 
-// Targets per lane of the vector-pipe kernel (centered_kernel.hpp): 64 T Morton-consecutive targets share a centre and every staged tile.  fp64: FOUR — half the
-// per-tile staging and LDS reads per pair for a somewhat larger cluster; the full-precision kernel still fits four waves per SIMD (125 registers), the others three.
-// A/B on one box (tools/ab_centered_T.py, profiles/r03_ab_centered_T.txt; T = 2 -> 4 -> 8): Laplace SL 2^20 x 2^20 405.4 -> 397.7 -> 405.9 ms at full precision,
-// 383.6 -> 369.5 -> 379.4 ms at 10 digits; double layer 563.9 -> 542.5 -> 534.1 ms; 2^18 x 2^18 and 2^20 x 2^14 level or 2-3 % faster; 2^17 x 2^20 +1 % at full
-// precision, -1.5 % at 10 digits.  fp32 keeps two: its far pairs are written as ONE packed stream over exactly two targets, and its default accuracy runs on the
-// matrix cores anyway.
-template <class R> constexpr int kCenteredT = sizeof(R) == 8 ? 4 : 2;
+// Targets per lane of the vector-pipe kernel (centered_kernel.hpp): 64 T Morton-consecutive targets share a centre and every staged tile.  fp64 single and double
+// layer: FOUR — half the per-tile staging and LDS reads per pair for a somewhat larger cluster; the full-precision kernel still fits four waves per SIMD (125
+// registers), the others three.  A/B on one box (profiles/r03_ab_centered_T.txt; T = 2 -> 4 -> 8): Laplace SL 2^20 x 2^20 405.4 -> 397.7 -> 405.9 ms at full
+// precision, 383.6 -> 369.5 -> 379.4 ms at 10 digits; double layer 563.9 -> 542.5 -> 534.1 ms.  fp32 keeps two: its far pairs are written as ONE packed stream over
+// exactly two targets, and its default accuracy runs on the matrix cores anyway.  The gradient kernel (round 4) takes three.  Each policy says so itself (targets_per_lane).
 
 namespace {
 // fp32 Laplace single and double layer at the seed's accuracy take the kernel whose contractions run on the bf16 matrix cores
@@ -44,7 +42,10 @@ int centered_pipe(int kernel_id, int real, int mode) {
 // once it keeps three waves per SIMD at that size (centered_mfma_kernel.hpp).  A/B on one box, profiles/r03_ab_mfma_variants.txt, r03_ab_mfma_sl_occupancy.txt.
 // SCTL_AMD_MFMA_CB=4 / 8 overrides (A/B runs).
 int centered_targets_per_wave(int kernel_id, int real, int mode) {
-  if (centered_pipe(kernel_id, real, mode) != 2) return 64 * (real == 0 /* SCTL_AMD_F64 */ ? kCenteredT<double> : kCenteredT<float>);
+  if (centered_pipe(kernel_id, real, mode) != 2) {
+    if (kernel_id == Laplace3D_FxdU::ID) return 64 * CenteredFxdU<double>::targets_per_lane<double>();
+    return 64 * (real == 0 /* SCTL_AMD_F64 */ ? CenteredFxU<double>::targets_per_lane<double>() : CenteredFxU<float>::targets_per_lane<float>());
+  }
   if (const char* e = std::getenv("SCTL_AMD_MFMA_CB")) {
     if (e[0] == '8') return 256;
     if (e[0] == '4') return 128;
@@ -66,7 +67,7 @@ template <class CP, class R, int MODE> void launch_centered(const EvalArgs<R>& a
       return;
     }
   }
-  hipLaunchKernelGGL((centered_kernel<CP, R, MODE, kCenteredT<R>>), grid, dim3(kWaveBlock), 0, st, a);
+  hipLaunchKernelGGL((centered_kernel<CP, R, MODE, CP::template targets_per_lane<R>()>), grid, dim3(kWaveBlock), 0, st, a);
 }
 }  // namespace
 
@@ -99,6 +100,7 @@ template <class CP, class R>
 hipError_t eval_centered_t(int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* xn, const R* f, R* v_trg, double scale_d, int mode, int cus,
                            hipStream_t st, bool presorted) {
   const R scale = (R)scale_d;
+  constexpr int K1 = CP::Ker::K1;
   int T, splits;
   int64_t chunk;
   centered_plan(Nt, Ns, cus, (int)sizeof(R) * (3 + CP::Ker::ND + CP::Ker::K0), &T, &splits, &chunk);
@@ -106,7 +108,7 @@ hipError_t eval_centered_t(int64_t Nt, int64_t Ns, const R* xt, const R* xs, con
     R* partial = nullptr;
     if (splits > 1) {
       void* base = nullptr;
-      CENTERED_TRY(workspace_acquire(st, sizeof(R) * (size_t)splits * (size_t)Nt, &base));
+      CENTERED_TRY(workspace_acquire(st, sizeof(R) * (size_t)splits * (size_t)Nt * K1, &base));
       partial = (R*)base;
     }
     EvalArgs<R> a{};
@@ -120,7 +122,7 @@ hipError_t eval_centered_t(int64_t Nt, int64_t Ns, const R* xt, const R* xs, con
     else launch_centered<CP, R, (sizeof(R) == 8 ? 2 : 1)>(a, grid, st);
     CENTERED_TRY(hipGetLastError());
     if (splits > 1)
-      hipLaunchKernelGGL((reduce_splits_kernel<R>), dim3((unsigned)((Nt + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, v_trg, (const R*)partial, Nt, splits, scale);
+      hipLaunchKernelGGL((reduce_splits_kernel<R>), dim3((unsigned)((Nt * K1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, v_trg, (const R*)partial, Nt * K1, splits, scale);
     return hipGetLastError();
   }
   const int nblk_box = 256;
@@ -130,24 +132,24 @@ hipError_t eval_centered_t(int64_t Nt, int64_t Ns, const R* xt, const R* xs, con
                                          63, st));
   const size_t n = (size_t)Nt;
   const size_t total = Carver::pad(sizeof(double) * 6 * nblk_box) + 2 * Carver::pad(sizeof(uint64_t) * n) + 2 * Carver::pad(sizeof(uint32_t) * n) +
-                       Carver::pad(sizeof(R) * 3 * n) + Carver::pad(sizeof(R) * n) + Carver::pad(tmp_bytes) +
-                       (splits > 1 ? Carver::pad(sizeof(R) * (size_t)splits * n) : 0);
+                       Carver::pad(sizeof(R) * 3 * n) + Carver::pad(sizeof(R) * n * K1) + Carver::pad(tmp_bytes) +
+                       (splits > 1 ? Carver::pad(sizeof(R) * (size_t)splits * n * K1) : 0);
   void* base = nullptr;
   CENTERED_TRY(workspace_acquire(st, total, &base));
   Carver cut(base);
   double* part = cut.take<double>(6 * nblk_box);
   uint64_t *keys = cut.take<uint64_t>(n), *keys2 = cut.take<uint64_t>(n);
   uint32_t *idx = cut.take<uint32_t>(n), *idx2 = cut.take<uint32_t>(n);
-  R *xts = cut.take<R>(3 * n), *outs = cut.take<R>(n);
+  R *xts = cut.take<R>(3 * n), *outs = cut.take<R>(n * K1);
   char* tmp = cut.take<char>(tmp_bytes);
-  R* partial = (splits > 1) ? cut.take<R>((size_t)splits * n) : nullptr;
+  R* partial = (splits > 1) ? cut.take<R>((size_t)splits * n * K1) : nullptr;
 
   hipLaunchKernelGGL((bbox_partial_kernel<R>), dim3(nblk_box), dim3(kBlock), 0, st, xt, Nt, part);
   hipLaunchKernelGGL((morton_keys_kernel<R>), dim3(nb), dim3(kBlock), 0, st, xt, Nt, (const double*)part, nblk_box, keys, idx);
   CENTERED_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, idx, idx2, (size_t)Nt, 0, 63, st));
   const uint32_t* perm = idx2;
   hipLaunchKernelGGL((gather_points_kernel<R>), dim3(nb), dim3(kBlock), 0, st, xt, perm, Nt, xts);
-  CENTERED_TRY(hipMemsetAsync(outs, 0, sizeof(R) * Nt, st));
+  CENTERED_TRY(hipMemsetAsync(outs, 0, sizeof(R) * Nt * K1, st));
 
   EvalArgs<R> a{};
   a.Nt = Nt; a.Ns = Ns; a.xt = xts; a.xs = xs; a.xn = xn; a.f = f; a.v_trg = outs; a.partial = nullptr;
@@ -161,8 +163,8 @@ hipError_t eval_centered_t(int64_t Nt, int64_t Ns, const R* xt, const R* xs, con
   else launch_centered<CP, R, (sizeof(R) == 8 ? 2 : 1)>(a, grid, st);
   CENTERED_TRY(hipGetLastError());
   if (splits > 1)
-    hipLaunchKernelGGL((reduce_splits_kernel<R>), dim3(nb), dim3(kBlock), 0, st, outs, (const R*)a.partial, Nt, splits, scale);
-  hipLaunchKernelGGL((scatter_add_kernel<R>), dim3(nb), dim3(kBlock), 0, st, (const R*)outs, perm, Nt, 1, v_trg);
+    hipLaunchKernelGGL((reduce_splits_kernel<R>), dim3((unsigned)((Nt * K1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, outs, (const R*)a.partial, Nt * K1, splits, scale);
+  hipLaunchKernelGGL((scatter_add_kernel<R>), dim3(nb), dim3(kBlock), 0, st, (const R*)outs, perm, Nt, K1, v_trg);
   return hipGetLastError();
 }
 // Morton order of n points that are ALREADY on the current device: bbox -> 63-bit keys -> rocPRIM radix sort (stable: ties keep the caller's
@@ -199,6 +201,9 @@ template <class R>
 hipError_t eval_centered(int kernel_id, int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* xn, const R* f, R* v_trg, double scale, int mode, int cus,
                          hipStream_t st, bool presorted) {
   if (kernel_id == Laplace3D_DxU::ID) return eval_centered_t<CenteredDxU<R>, R>(Nt, Ns, xt, xs, xn, f, v_trg, scale, mode, cus, st, presorted);
+  if constexpr (std::is_same<R, double>::value) {   // vector outputs: fp64 (capi.hip: has_centered_path)
+    if (kernel_id == Laplace3D_FxdU::ID) return eval_centered_t<CenteredFxdU<R>, R>(Nt, Ns, xt, xs, xn, f, v_trg, scale, mode, cus, st, presorted);
+  }
   return eval_centered_t<CenteredFxU<R>, R>(Nt, Ns, xt, xs, xn, f, v_trg, scale, mode, cus, st, presorted);
 }
 template hipError_t eval_centered<double>(int, int64_t, int64_t, const double*, const double*, const double*, const double*, double*, double, int, int, hipStream_t, bool);

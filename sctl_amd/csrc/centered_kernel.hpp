@@ -125,17 +125,21 @@ template <> struct FarTargets<float, 2> {
   }
 };
 
-// What a kernel needs to run on the centred path (scalar potentials, K1 = 1): besides {x', y', z', |x_s'|^2} a far source
-// carries XW more reals, written by put_extra / put_null and read once per source by load_extra; far_pair is the pair
-// evaluation from the centred quantities.  Near sources go through the kernel's own exact pair (Ker::pack / Ker::pair).
+// What a kernel needs to run on the centred path: besides {x', y', z', |x_s'|^2} a far source carries XW more reals, written by put_extra /
+// put_null and read once per source by load_extra; far_pair is the pair evaluation from the centred quantities into NF far accumulators per
+// target.  Near sources go through the kernel's own exact pair (Ker::pack / Ker::pair) into K1 accumulators.  A scalar kernel (NF = K1 = 1) adds
+// both into one sum; a kernel whose output needs x_t - x_s itself (a gradient) accumulates MOMENTS over the far sources — with
+// x_t - x_s = x_t' - x_s', sum_s A_s (x_t - x_s) = x_t' sum_s A_s - sum_s A_s x_s': no cancellation, |x_t'| <= Rt < |x_s'| / 2 — and finish()
+// puts the K1 outputs together once, when the sums leave the registers.  NEAR_CAP: capacity of the per-wave list of pending near sources.
 template <class R> struct CenteredFxU {      // u += f / r
   using Ker = Laplace3D_FxU;
   // fp32 keeps the density twice, {f, f}: the packed accumulate then takes it as a register pair as it comes from LDS (the compiler
   // copied the odd ones of four densities read together into fresh registers to broadcast them)
   static constexpr bool DUP = std::is_same<R, float>::value;
-  static constexpr int XW = DUP ? 2 : 1;
+  static constexpr int XW = DUP ? 2 : 1, NF = 1, NEAR_CAP = 128;
+  template <class RR> static constexpr int targets_per_lane() { return sizeof(RR) == 8 ? 4 : 2; }
   struct Extra { R f, f2; };
-  static __device__ __forceinline__ void put_extra(R* base, int q, const R (&)[3], const R*, const R* f) {
+  template <int MODE> static __device__ __forceinline__ void put_extra(R* base, int q, const R (&)[3], const R*, const R* f) {
     if (DUP) { base[2 * q] = f[0]; base[2 * q + 1] = f[0]; }
     else base[q] = f[0];
   }
@@ -153,26 +157,27 @@ template <class R> struct CenteredFxU {      // u += f / r
     acc = fma_(e.f, rsqrt_scaled<MODE, false>(r2, K), acc);   // MODE 1: 2/r, MODE 2: (8/3)/r, as Ker::pair (acc_factor)
   }
   // all T targets of the lane against one far source
-  template <int MODE, int T> static __device__ __forceinline__ void far_pairs(R (&acc)[T], const FarTargets<R, T>& tg, const R (&b)[4], const Extra& e,
-                                                                                const RsqConst<R>& K) {
+  template <int MODE, int T, class KC> static __device__ __forceinline__ void far_pairs(R (&acc)[T][NF], const FarTargets<R, T>& tg, const R (&b)[4], const Extra& e,
+                                                                                          const KC& K) {
     if constexpr (std::is_same<R, float>::value && T == 2) {
       f32x2 r2 = pk_add_hi(tg.tp, f32x2{b[2], b[3]});
       r2 = tg.mp[2] * f32x2{b[2], b[2]} + r2;
       r2 = tg.mp[1] * f32x2{b[1], b[1]} + r2;
       r2 = tg.mp[0] * f32x2{b[0], b[0]} + r2;
-      const f32x2 a = f32x2{acc[0], acc[1]} + f32x2{e.f, e.f2} * rsqrt_pair<MODE>(r2);
-      acc[0] = a[0]; acc[1] = a[1];
+      const f32x2 a = f32x2{acc[0][0], acc[1][0]} + f32x2{e.f, e.f2} * rsqrt_pair<MODE>(r2);
+      acc[0][0] = a[0]; acc[1][0] = a[1];
     } else {
 #pragma unroll
-      for (int j = 0; j < T; j++) far_pair<MODE>(acc[j], tg.m2x[j], tg.tt[j], b, e, K);
+      for (int j = 0; j < T; j++) far_pair<MODE>(acc[j][0], tg.m2x[j], tg.tt[j], b, e, K.rsq);
     }
   }
 };
 template <class R> struct CenteredDxU {      // u += ((x_t - x_s).n f) / r^3, with (x_t - x_s).n f = x_t'.nf - x_s'.nf
   using Ker = Laplace3D_DxU;
-  static constexpr int XW = 4;               // {-nf/2 (3 components, to be dotted with m2x = -2 x_t'), -(x_s'.nf)}
+  static constexpr int XW = 4, NF = 1, NEAR_CAP = 128;   // XW: {-nf/2 (3 components, to be dotted with m2x = -2 x_t'), -(x_s'.nf)}
+  template <class RR> static constexpr int targets_per_lane() { return sizeof(RR) == 8 ? 4 : 2; }
   struct Extra { R g[4]; };
-  static __device__ __forceinline__ void put_extra(R* base, int q, const R (&p)[3], const R* n, const R* f) {
+  template <int MODE> static __device__ __forceinline__ void put_extra(R* base, int q, const R (&p)[3], const R* n, const R* f) {
     const R nf[3] = {n[0] * f[0], n[1] * f[0], n[2] * f[0]};
     Rec4<R>::put((typename Rec4<R>::V*)base + q * Rec4<R>::NW, R(-0.5) * nf[0], R(-0.5) * nf[1], R(-0.5) * nf[2], -(p[0] * nf[0] + p[1] * nf[1] + p[2] * nf[2]));
   }
@@ -191,8 +196,8 @@ template <class R> struct CenteredDxU {      // u += ((x_t - x_s).n f) / r^3, wi
     const R dn = fma_(m2x[0], e.g[0], fma_(m2x[1], e.g[1], fma_(m2x[2], e.g[2], e.g[3])));
     acc = fma_(dn, y3, acc);
   }
-  template <int MODE, int T> static __device__ __forceinline__ void far_pairs(R (&acc)[T], const FarTargets<R, T>& tg, const R (&b)[4], const Extra& e,
-                                                                                const RsqConst<R>& K) {
+  template <int MODE, int T, class KC> static __device__ __forceinline__ void far_pairs(R (&acc)[T][NF], const FarTargets<R, T>& tg, const R (&b)[4], const Extra& e,
+                                                                                          const KC& K) {
     if constexpr (std::is_same<R, float>::value && T == 2) {
       const f32x2 mx = tg.mp[0], my = tg.mp[1], mz = tg.mp[2];
       f32x2 r2 = pk_add_hi(tg.tp, f32x2{b[2], b[3]});
@@ -203,14 +208,76 @@ template <class R> struct CenteredDxU {      // u += ((x_t - x_s).n f) / r^3, wi
       f32x2 dn = pk_fma_lo_hi(mz, f32x2{e.g[2], e.g[3]});
       dn = my * f32x2{e.g[1], e.g[1]} + dn;
       dn = mx * f32x2{e.g[0], e.g[0]} + dn;
-      const f32x2 a = f32x2{acc[0], acc[1]} + dn * (y * y * y);
-      acc[0] = a[0]; acc[1] = a[1];
+      const f32x2 a = f32x2{acc[0][0], acc[1][0]} + dn * (y * y * y);
+      acc[0][0] = a[0]; acc[1][0] = a[1];
     } else {
 #pragma unroll
-      for (int j = 0; j < T; j++) far_pair<MODE>(acc[j], tg.m2x[j], tg.tt[j], b, e, K);
+      for (int j = 0; j < T; j++) far_pair<MODE>(acc[j][0], tg.m2x[j], tg.tt[j], b, e, K.rsq);
     }
   }
 };
+
+// ---- vector outputs: moments over the far sources (fp64; the fp32 forms of these kernels keep the exact path) ----------------------------------------------
+// XW reals of a far record as whole 16-byte words
+template <class R, int XW> struct ExtraWords {
+  static_assert(XW % 4 == 0, "whole Rec4 groups");
+  struct Extra { R g[XW]; };
+  static __device__ __forceinline__ Extra load_extra(const R* base, int s) {
+    Extra e;
+#pragma unroll
+    for (int w = 0; w < XW / 4; w++) {
+      R v[4];
+      Rec4<R>::get((const typename Rec4<R>::V*)base + (s * (XW / 4) + w) * Rec4<R>::NW, v);
+      e.g[4 * w] = v[0]; e.g[4 * w + 1] = v[1]; e.g[4 * w + 2] = v[2]; e.g[4 * w + 3] = v[3];
+    }
+    return e;
+  }
+  static __device__ __forceinline__ void store_extra(R* base, int q, const Extra& e) {
+#pragma unroll
+    for (int w = 0; w < XW / 4; w++)
+      Rec4<R>::put((typename Rec4<R>::V*)base + (q * (XW / 4) + w) * Rec4<R>::NW, e.g[4 * w], e.g[4 * w + 1], e.g[4 * w + 2], e.g[4 * w + 3]);
+  }
+  static __device__ __forceinline__ void put_null(R* base, int q) {
+    Extra e;
+#pragma unroll
+    for (int k = 0; k < XW; k++) e.g[k] = R(0);
+    store_extra(base, q, e);
+  }
+};
+// gradient of the single layer, u_j = sum_s f_s (x_t - x_s)_j / r^3 (kernel_functions.hpp:53-72): with A = f / r^3 the far sources give
+// u_j = x_t'_j S0 - S_j, S0 = sum A, S_j = sum A x_s'_j; the record carries {f, f x', f y', f z'}, so a far pair is the 4-instruction distance, the
+// reciprocal cube and FOUR accumulations: 17 issue slots where the exact pair has 19 (3 differences + 3 for r^2, one product f / r^3, 3 accumulations)
+template <class R> struct CenteredFxdU : ExtraWords<R, 4> {
+  using Ker = Laplace3D_FxdU;
+  using Extra = typename ExtraWords<R, 4>::Extra;
+  static constexpr int XW = 4, NF = 4, NEAR_CAP = 128;
+  // three targets per lane: a far record is four 16-byte words, so with two targets the loop is close to the LDS read rate, and four cost the registers of a third
+  // wave per SIMD; against the exact kernel, one box: T = 2 +2.2 .. 2.5 %, T = 3 +4.3 .. 4.6 %, T = 4 +3.2 .. 4.1 % (2^18 and 2^20, profiles/r04_ab_centered_vec.txt)
+  template <class RR> static constexpr int targets_per_lane() { return 3; }
+  template <int MODE> static __device__ __forceinline__ void put_extra(R* base, int q, const R (&p)[3], const R*, const R* f) {
+    Extra e{{f[0], f[0] * p[0], f[0] * p[1], f[0] * p[2]}};
+    ExtraWords<R, 4>::store_extra(base, q, e);
+  }
+  template <int MODE, int T, class KC> static __device__ __forceinline__ void far_pairs(R (&acc)[T][NF], const FarTargets<R, T>& tg, const R (&b)[4], const Extra& e,
+                                                                                          const KC& K) {
+#pragma unroll
+    for (int j = 0; j < T; j++) {
+      const R r2 = fma_(tg.m2x[j][0], b[0], fma_(tg.m2x[j][1], b[1], fma_(tg.m2x[j][2], b[2], tg.tt[j] + b[3])));
+      const R y3 = rsqrt_pow_scaled<MODE, 3, false>(r2, K.rsq);        // the factor Ker::acc_factor(MODE) accounts for, as Ker::pair
+#pragma unroll
+      for (int k = 0; k < 4; k++) acc[j][k] = fma_(y3, e.g[k], acc[j][k]);
+    }
+  }
+  // out = near + far: x_t' = -m2x / 2
+  template <int MODE> static __device__ __forceinline__ void finish(R (&out)[3], const R (&far)[NF], const R (&near)[3], const R (&m2x)[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) out[k] = near[k] + fma_(R(-0.5) * m2x[k], far[0], -far[1 + k]);
+  }
+};
+// (The fused single + double layer kernel, potential and gradient — BASELINE config 2 — was written the same way and is NOT kept: u = sum y (q' + w) and
+// grad_j = sum y^3 (m'_j + c x_s'_j) - x_t'_j sum y^3 c cost 28 issue slots per far pair where the exact pair has 29 — the two distance slots saved pay for the
+// extra moment sum y^3 c — and with the near pairs, a 12-real near record and six LDS words per far source it measured 2.5 .. 3.7 % SLOWER than the exact kernel at
+// 2^18 and 2^20: profiles/r04_ab_centered_vec.txt.)
 
 // a.xt: Morton-sorted targets; a.v_trg / a.partial: indexed like a.xt (the caller scatters back).
 // (asking the compiler for 5-6 waves/SIMD instead of the 4 its registers allow, or unrolling the far loop by 2 or 8 instead of 4, costs 0-3 %:
@@ -220,8 +287,9 @@ __global__ void __launch_bounds__(kWaveBlock) centered_kernel(const EvalArgs<R> 
   using V = typename Rec4<R>::V;
   constexpr int NW = Rec4<R>::NW;
   using Ker = typename CP::Ker;
-  static_assert(Ker::K1 == 1 && Ker::K0 == 1, "the centred path is written for scalar densities and potentials");
-  constexpr int ND = Ker::ND;
+  constexpr int ND = Ker::ND, K0 = Ker::K0, K1 = Ker::K1, NF = CP::NF;
+  constexpr bool SCALAR = (K1 == 1 && NF == 1);               // far and near pairs add into ONE sum per target (the Laplace single and double layer)
+  constexpr int kNearCap = CP::NEAR_CAP < sctl_amd::kNearCap ? CP::NEAR_CAP : sctl_amd::kNearCap;
   constexpr int NEARW = (Ker::NREC + 3) / 4;                  // Rec4 groups of a near record (the kernel's packed exact record)
   constexpr int XV = (CP::XW * (int)sizeof(R) + 15) / 16;     // 16-byte words of the extra far record
   __shared__ V farB[(kWaveTile + UNR) * NW];                  // {x', y', z', |x_s'|^2}   (+ the leftovers of earlier tiles)
@@ -277,9 +345,15 @@ __global__ void __launch_bounds__(kWaveBlock) centered_kernel(const EvalArgs<R> 
   rt2 = uniform_(wave_max(rt2));
   const R near_r2 = R(a.ctx.v[0]) * rt2;   // ctx.v[0] = kNearFactor2; NaN coordinates fail every comparison => "near" => exact path
 
-  R acc[T][1];
+  R acc[T][K1];                      // the exact (near) pairs' sums; a scalar kernel's far sums too
+  R facc[T][SCALAR ? 1 : NF];        // the far pairs' moments (vector outputs)
 #pragma unroll
-  for (int j = 0; j < T; j++) acc[j][0] = 0;
+  for (int j = 0; j < T; j++) {
+#pragma unroll
+    for (int k = 0; k < K1; k++) acc[j][k] = 0;
+#pragma unroll
+    for (int k = 0; k < (SCALAR ? 1 : NF); k++) facc[j][k] = 0;
+  }
 
   const int64_t s_begin = (int64_t)split_idx * a.chunk;
   const int64_t s_end = (s_begin + a.chunk < a.Ns) ? s_begin + a.chunk : a.Ns;
@@ -287,7 +361,9 @@ __global__ void __launch_bounds__(kWaveBlock) centered_kernel(const EvalArgs<R> 
   const int ntile = (int)((len + kWaveTile - 1) / kWaveTile);
 
   // software pipeline: the next tile's source is loaded into registers while the current tile is evaluated
-  R x[3] = {0, 0, 0}, nrm[3] = {0, 0, 0}, f[1] = {0};
+  R x[3] = {0, 0, 0}, nrm[3] = {0, 0, 0}, f[K0];
+#pragma unroll
+  for (int k = 0; k < K0; k++) f[k] = 0;
   auto load_source = [&](int it) {
     const int64_t s = s_begin + (int64_t)it * kWaveTile + lane;
     if (s < s_end) {
@@ -295,14 +371,15 @@ __global__ void __launch_bounds__(kWaveBlock) centered_kernel(const EvalArgs<R> 
       for (int k = 0; k < 3; k++) x[k] = a.xs[s * 3 + k];
 #pragma unroll
       for (int k = 0; k < ND; k++) nrm[k] = a.xn[s * ND + k];
-      f[0] = a.f[s];
+#pragma unroll
+      for (int k = 0; k < K0; k++) f[k] = a.f[s * K0 + k];
     }
   };
   if (ntile > 0) load_source(0);
 
   // ---- near sources: the reference-exact pair (d = x_t - x_s, masked at r = 0), evaluated in batches -----------
   const R far_off = R(1.0e3) * (R(1) + sqrt_(rt2));
-  auto put_near = [&](int q, const R (&xq)[3], const R (&nq)[3], const R (&fq)[1]) {
+  auto put_near = [&](int q, const R (&xq)[3], const R (&nq)[3], const R (&fq)[K0]) {
     R rec[4 * NEARW] = {};
     pack_record<Ker, R, MODE>(rec, xq, nq, fq);
 #pragma unroll
@@ -312,7 +389,7 @@ __global__ void __launch_bounds__(kWaveBlock) centered_kernel(const EvalArgs<R> 
   auto flush_near = [&]() {
     if (nn & 1) {   // pad to an even count with a null source
       if (lane == 0) {
-        const R xq[3] = {c[0] + far_off, c[1], c[2]}, nq[3] = {0, 0, 0}, fq[1] = {0};
+        const R xq[3] = {c[0] + far_off, c[1], c[2]}, nq[3] = {0, 0, 0}, fq[K0] = {};
         put_near(nn, xq, nq, fq);
       }
       __syncthreads();
@@ -375,7 +452,7 @@ __global__ void __launch_bounds__(kWaveBlock) centered_kernel(const EvalArgs<R> 
     if (is_far) {
       const int q = carry + __popcll(bf & below);
       Rec4<R>::put(farB + q * NW, p[0], p[1], p[2], ss);
-      CP::put_extra(farX, q, p, nrm, f);
+      CP::template put_extra<MODE>(farX, q, p, nrm, f);
     } else if (is_near) {
       put_near(nn + __popcll(bn & below), x, nrm, f);
     }
@@ -385,20 +462,28 @@ __global__ void __launch_bounds__(kWaveBlock) centered_kernel(const EvalArgs<R> 
   // records [0, m) of the far list, m a multiple of UNR: the 4-instruction distance, no mask.  Per-call partial sums, folded into acc at the
   // end (two-level summation: matters for fp32 at Ns = 2^23)
   auto run_far = [&](int m) {
-    R tacc[T];
+    R tacc[T][NF];
 #pragma unroll
-    for (int j = 0; j < T; j++) tacc[j] = 0;
+    for (int j = 0; j < T; j++)
+#pragma unroll
+      for (int k = 0; k < NF; k++) tacc[j][k] = 0;
     for (int s = 0; s < m; s += UNR) {
 #pragma unroll
       for (int u = 0; u < UNR; u++) {
         R b[4];
         Rec4<R>::get(farB + (s + u) * NW, b);
         const typename CP::Extra e = CP::load_extra(farX, s + u);
-        CP::template far_pairs<MODE, T>(tacc, tg, b, e, K.rsq);
+        CP::template far_pairs<MODE, T>(tacc, tg, b, e, K);
       }
     }
 #pragma unroll
-    for (int j = 0; j < T; j++) acc[j][0] += tacc[j];
+    for (int j = 0; j < T; j++) {
+      if constexpr (SCALAR) acc[j][0] += tacc[j][0];
+      else {
+#pragma unroll
+        for (int k = 0; k < NF; k++) facc[j][k] += tacc[j][k];
+      }
+    }
   };
   auto put_null_far = [&](int q) { Rec4<R>::put(farB + q * NW, far_off, R(0), R(0), far_off * far_off); CP::put_null(farX, q); };   // zero density at ~1e3 cluster radii: contributes exactly 0
 
@@ -442,9 +527,22 @@ __global__ void __launch_bounds__(kWaveBlock) centered_kernel(const EvalArgs<R> 
 #pragma unroll
   for (int j = 0; j < T; j++) {
     const int64_t t = tbase + j * kWaveBlock + lane;
-    if (t < a.Nt) {
-      if (gridDim.y == 1) a.v_trg[t] += acc[j][0] * a.scale;
-      else a.partial[(int64_t)split_idx * a.Nt + t] = acc[j][0];
+    if constexpr (SCALAR) {
+      if (t < a.Nt) {
+        if (gridDim.y == 1) a.v_trg[t] += acc[j][0] * a.scale;
+        else a.partial[(int64_t)split_idx * a.Nt + t] = acc[j][0];
+      }
+    } else {
+      R out[K1];
+      CP::template finish<MODE>(out, facc[j], acc[j], tg.m2x[j]);
+      finish_acc<Ker, R, MODE>(out);          // (what the kernel itself leaves for the end, e.g. the fused kernel's factor on its potential)
+      if (t < a.Nt) {
+#pragma unroll
+        for (int k = 0; k < K1; k++) {
+          if (gridDim.y == 1) a.v_trg[t * K1 + k] += out[k] * a.scale;
+          else a.partial[((int64_t)split_idx * a.Nt + t) * K1 + k] = out[k];
+        }
+      }
     }
   }
 }

@@ -75,7 +75,7 @@ def test_launch_planner():
         for real in (0, 1):
             for N in (1, 300, 1 << 14, 1 << 18, 1 << 20, 1 << 23):
                 p = sctl_amd.plan(name, real, N, N)
-                assert p["trg_per_lane"] in (1, 2, 4) and p["src_splits"] >= 1
+                assert p["trg_per_lane"] in (1, 2, 3, 4) and p["src_splits"] >= 1
                 if p["path"] == "exact":
                     assert p["workgroups"] >= min(1024, ((N + 255) // 256) * ((N + 255) // 256))
                 k1 = sctl_amd.kernel_info(name)["k1"]
@@ -98,7 +98,10 @@ def test_launch_planner():
         assert head["path"] == "tile-centred" and head["src_splits"] == 16 and head["workgroups"] == 4096 * 16 and head["trg_per_lane"] == 4   # 256 targets per wave (fp64)
         assert sctl_amd.plan("Laplace3D-FxU", 1, 1 << 20, 1 << 20)["path"] == "tile-centred"
         assert sctl_amd.plan("Laplace3D-DxU", 0, 1 << 20, 1 << 20)["path"] == "tile-centred"  # scalar Laplace kernels have a centred form
-        assert sctl_amd.plan("Laplace3D-FxdU", 0, 1 << 20, 1 << 20)["path"] == "exact"        # the gradient needs x_t - x_s anyway
+        grad = sctl_amd.plan("Laplace3D-FxdU", 0, 1 << 20, 1 << 20)                           # the gradient: far sources as moments (round 4), three targets per lane, fp64 only
+        assert grad["path"] == "tile-centred" and grad["trg_per_lane"] == 3 and grad["workspace_bytes"] == grad["src_splits"] * 3 * 8 << 20
+        assert sctl_amd.plan("Laplace3D-FxdU", 1, 1 << 20, 1 << 20)["path"] == "exact"
+        assert sctl_amd.plan("Laplace3D-FDxUdU", 0, 1 << 20, 1 << 20)["path"] == "exact"      # its centred form measured slower than the exact kernel
         # which units run the far pairs (sctl_amd_eval_pipe): the bf16 matrix cores only for fp32 scalar Laplace at the seed's accuracy
         if os.environ.get("SCTL_AMD_MFMA_F32") != "0":
             for name in ("Laplace3D-FxU", "Laplace3D-DxU"):

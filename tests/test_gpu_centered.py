@@ -37,15 +37,18 @@ def _clouds(kind, rng):
 
 
 @pytest.mark.parametrize("kind", ["uniform", "clustered", "surface", "identical_targets", "offset"])
-@pytest.mark.parametrize("name", ["Laplace3D-FxU", "Laplace3D-DxU"])
+@pytest.mark.parametrize("name", ["Laplace3D-FxU", "Laplace3D-DxU", "Laplace3D-FxdU"])
 def test_centred_path_matches_oracle_and_exact_kernel(O, name, kind):
+    """(the gradient kernel, round 4: its far sources are summed as moments, x_t' sum A - sum A x_s'; fp64 only)"""
     import torch
     rng = np.random.default_rng(123)
     xt, xs = _clouds(kind, rng)
     xt, xs = np.ascontiguousarray(xt.ravel()), np.ascontiguousarray(xs.ravel())
-    f = rng.random(NS) - 0.5
-    xn = (rng.random(NS * 3) - 0.5) if name.endswith("DxU") else None
+    info = sctl_amd.kernel_info(name)
+    f = rng.random(NS * info["k0"]) - 0.5
+    xn = (rng.random(NS * 3) - 0.5) if info["nd"] else None
     assert sctl_amd.plan(name, 0, NT, NS)["path"] == "tile-centred"
+    assert sctl_amd.plan(name, 1, NT, NS)["path"] == ("tile-centred" if info["k1"] == 1 else "exact")      # vector outputs: fp64 only
     d = [None if a is None else torch.from_numpy(a).cuda() for a in (xt, xs, xn, f)]
     u = sctl_amd.eval_device(name, *d).cpu().numpy()
     assert np.all(np.isfinite(u))
@@ -59,7 +62,13 @@ def test_centred_path_matches_oracle_and_exact_kernel(O, name, kind):
     assert rel_l2(u, u_exact) <= (2e-14 if name.endswith("FxU") else 2e-13), rel_l2(u, u_exact)
     sel = rng.choice(NT, 300, replace=False)
     ref = O.eval(name, xt.reshape(NT, 3)[sel].ravel().copy(), xs, xn, f)
-    assert rel_l2(u[sel], ref) <= 1e-12, rel_l2(u[sel], ref)
+    assert rel_l2(u.reshape(NT, -1)[sel].ravel(), ref) <= 1e-12, rel_l2(u.reshape(NT, -1)[sel].ravel(), ref)
+    if info["k1"] > 1:       # accuracy modes and accumulate semantics of the new policies (the scalar ones: the next test)
+        v0 = torch.from_numpy(rng.random(NT * info["k1"]) - 0.5).cuda()
+        u10 = sctl_amd.eval_device(name, *d, v_trg=v0.clone(), digits=10).cpu().numpy() - v0.cpu().numpy()
+        assert rel_l2(u10, u) <= 1e-9 and sctl_amd.plan(name, 0, NT, NS, digits=10)["path"] == "tile-centred"
+        u3 = sctl_amd.eval_device(name, *d, digits=3).cpu().numpy()
+        assert rel_l2(u3, u) <= 1e-2
 
 
 def test_centred_path_accumulates_and_honours_digits(O):
@@ -218,9 +227,9 @@ def test_centred_kernels_give_bit_identical_results_run_to_run(kind):
             if cb:
                 os.environ["SCTL_AMD_MFMA_CB"] = cb
             try:
-                for name in ("Laplace3D-FxU", "Laplace3D-DxU"):
+                for name in ("Laplace3D-FxU", "Laplace3D-DxU") + (("Laplace3D-FxdU",) if dt == np.float64 else ()):
                     pl = sctl_amd.plan(name, 1 if dt == np.float32 else 0, NT, NS)
-                    assert pl["path"] == "tile-centred" and pl["trg_per_lane"] == per_lane, (pl, mfma, cb)
+                    assert pl["path"] == "tile-centred" and pl["trg_per_lane"] == (3 if name.endswith("FxdU") else per_lane), (pl, mfma, cb)
                     assert pl["pipe"].startswith("bf16 matrix cores") == (dt == np.float32 and mfma == "1"), pl
                     runs = [sctl_amd.eval_device(name, d[0], d[1], d[2] if name.endswith("DxU") else None, d[3]).clone() for _ in range(6)]
                     assert bool(torch.isfinite(runs[0]).all())
