@@ -46,6 +46,8 @@ struct PackedGroup {    // one small target range and its sources
 };
 constexpr int kPackedLanes[4] = {8, 8, 16, 32};
 constexpr int kPackedTargets[4] = {1, 2, 2, 2};
+constexpr int kPackedSourcesPerLane[4] = {2, 2, 2, 1};          // per step: steps of 16, 16, 32, 32 sources per group
+constexpr int kPackedTileWords(int nv) { return 2 * kListTile * nv + 8; }   // 16-byte words of LDS: 8 groups x (16 records + 1)
 
 template <class R> struct ListArgs {
   int32_t xcd_first[9];   // items [xcd_first[x], xcd_first[x + 1]) are the share of XCD x (see lists_kernel)
@@ -233,14 +235,14 @@ __device__ __forceinline__ void lists_item(const ListArgs<R>& a, const ListItem&
 // A step runs without the r = 0 mask and is repaired when a coincident pair shows up, as in lists_item — except that a step KNOWN to hold coincident pairs is run
 // masked at once: when the caller's sources ARE its targets (launch-uniform: one array) a lane sees that the source it fetched is one of its group's own
 // targets.  With eight boxes per wave some group is at its own points in a third of the steps; evaluating those twice would cost more than the whole mask.
-template <class Ker, class R, int MODE, int P, int T, class KC, class V>
+template <class Ker, class R, int MODE, int P, int T, int SPL, class KC, class V>
 __device__ __forceinline__ void lists_packed_item(const ListArgs<R>& a, const ListItem& it, V* tile, const KC& K) {
   constexpr int K0 = Ker::K0, K1 = Ker::K1, ND = Ker::ND, NREC = Ker::NREC;
   constexpr int VN = VecOf<R>::N;
   constexpr int NV = (NREC + VN - 1) / VN;
   constexpr int NRECP = NV * VN;
-  constexpr int G = kListWave / P, SLICE = P * NV + 1;      // 16-byte words per group slice (+ 1: bank spread)
-  static_assert(G * SLICE <= kListTile * NV + 8, "the packed slices fit the list kernel's LDS tile");
+  constexpr int G = kListWave / P, S = P * SPL, SLICE = S * NV + 1;   // S sources per group and step (SPL per lane); 16-byte words per group slice (+ 1: bank spread)
+  static_assert(G * SLICE <= kPackedTileWords(NV), "the packed slices fit the list kernel's LDS tile");
   const int lane = threadIdx.x, g = lane / P, i = lane % P;
   const bool live = g < it.nt;                              // (it.nt = groups of this item)
   const PackedGroup pg = a.groups[it.t0 + (live ? g : 0)];
@@ -261,55 +263,72 @@ __device__ __forceinline__ void lists_packed_item(const ListArgs<R>& a, const Li
   int nmax = nsrc;                                          // the longest sequence of the wave decides the trip count
   for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(nmax, o); nmax = (w > nmax) ? w : nmax; }
   nmax = __builtin_amdgcn_readfirstlane(nmax);
-  const int nsteps = (nmax + P - 1) / P;
+  const int nsteps = (nmax + S - 1) / S;
 
-  R sx[3] = {0, 0, 0}, sn[3] = {0, 0, 0}, sf[K0];
+  R sx[SPL][3], sn[SPL][3], sf[SPL][K0];
 #pragma unroll
-  for (int k = 0; k < K0; k++) sf[k] = 0;
-  // The sources of a step are fetched one step ahead, their INDICES two steps ahead: index -> coordinates is a chain of two memory latencies, and a step of
-  // eight sources is short.  idx_next: this lane's source of the step after the one being gathered (-1: none).
-  bool own = false;    // the source this lane holds for the coming step is one of its group's targets
-  auto load_idx = [&](int step) -> int64_t {
-    const int q = step * P + i;
-    return (q < nsrc) ? (int64_t)a.flat[pg.flat_off + q] : (int64_t)-1;
+  for (int u = 0; u < SPL; u++) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) { sx[u][k] = 0; sn[u][k] = 0; }
+#pragma unroll
+    for (int k = 0; k < K0; k++) sf[u][k] = 0;
+  }
+  // The sources of a step are fetched one step ahead, their INDICES two steps ahead: index -> coordinates is a chain of two memory latencies, and a step
+  // is short.  Lane i of a group holds sources u P + i, u < SPL, of the step's S.  idx_next: its sources of the step after the one being gathered (-1: none).
+  bool own = false;    // a source this lane holds for the coming step is one of its group's targets
+  int64_t idx_next[SPL];
+  auto load_idx = [&](int step) {
+#pragma unroll
+    for (int u = 0; u < SPL; u++) {
+      const int q = step * S + u * P + i;
+      idx_next[u] = (q < nsrc) ? (int64_t)a.flat[pg.flat_off + q] : (int64_t)-1;
+    }
   };
-  int64_t idx_next = (nsteps > 0) ? load_idx(0) : (int64_t)-1;
+  if (nsteps > 0) load_idx(0);
   auto fetch = [&](int step) {
-    const int64_t src = idx_next;
-    idx_next = (step + 1 < nsteps) ? load_idx(step + 1) : (int64_t)-1;
+    int64_t src[SPL];
+#pragma unroll
+    for (int u = 0; u < SPL; u++) src[u] = idx_next[u];
+    if (step + 1 < nsteps) load_idx(step + 1);
     own = false;
-    if (src >= 0) {
-      own = self && src >= pg.t0 && src < pg.t0 + pg.nt;
 #pragma unroll
-      for (int k = 0; k < 3; k++) sx[k] = a.xs[src * 3 + k];
+    for (int u = 0; u < SPL; u++) {
+      if (src[u] >= 0) {
+        own = own || (self && src[u] >= pg.t0 && src[u] < pg.t0 + pg.nt);
 #pragma unroll
-      for (int k = 0; k < ND; k++) sn[k] = a.xn[src * ND + k];
+        for (int k = 0; k < 3; k++) sx[u][k] = a.xs[src[u] * 3 + k];
 #pragma unroll
-      for (int k = 0; k < K0; k++) sf[k] = a.f[src * K0 + k];
+        for (int k = 0; k < ND; k++) sn[u][k] = a.xn[src[u] * ND + k];
+#pragma unroll
+        for (int k = 0; k < K0; k++) sf[u][k] = a.f[src[u] * K0 + k];
+      }
     }
   };
   V* const slice = tile + g * SLICE;
   if (nsteps > 0) fetch(0);
   for (int step = 0; step < nsteps; step++) {
     __syncthreads();   // previous slices fully consumed
-    const int cnt = nsrc - step * P;                        // sources of this group in this step: >= P (full), 1 .. P - 1 (its last), <= 0 (done)
+    const int cnt = nsrc - step * S;                        // sources of this group in this step: >= S (full), 1 .. S - 1 (its last), <= 0 (done)
     const bool known_coincident = __any(own);               // (of the step being staged now: `own` belongs to the sources fetched for it)
-    if (i < cnt) {
-      R rec[NRECP] = {};
-      pack_record<Ker, R, MODE>(rec, sx, sn, sf);
 #pragma unroll
-      for (int v = 0; v < NV; v++) {
-        V w;
+    for (int u = 0; u < SPL; u++) {
+      if (u * P + i < cnt) {
+        R rec[NRECP] = {};
+        pack_record<Ker, R, MODE>(rec, sx[u], sn[u], sf[u]);
 #pragma unroll
-        for (int e = 0; e < VN; e++) w[e] = rec[v * VN + e];
-        slice[i * NV + v] = w;
+        for (int v = 0; v < NV; v++) {
+          V w;
+#pragma unroll
+          for (int e = 0; e < VN; e++) w[e] = rec[v * VN + e];
+          slice[(u * P + i) * NV + v] = w;
+        }
       }
     }
     if (step + 1 < nsteps) fetch(step + 1);
     __syncthreads();
 
     R tacc[T][K1];
-    const bool full = __all(cnt >= P);                      // wave-uniform: every group has a whole slice (all steps but the groups' last ones)
+    const bool full = __all(cnt >= S);                      // wave-uniform: every group has a whole slice (all steps but the groups' last ones)
     auto run_step_v = [&](auto masked_tag, auto variant_tag) {
       constexpr bool MASKED = decltype(masked_tag)::value;
       constexpr int VARIANT = decltype(variant_tag)::value;
@@ -335,9 +354,12 @@ __device__ __forceinline__ void lists_packed_item(const ListArgs<R>& a, const Li
       };
       if (full) {
 #pragma unroll UnrollOf<T, Ker::K1>::value
-        for (int s = 0; s < P; s++) one_source(s);
-      } else {
-        for (int s = 0; s < P; s++)
+        for (int s = 0; s < S; s++) one_source(s);
+      } else {                                              // a group's last step: its remaining sources, the other groups' lanes idle
+        int cmax = cnt;
+        for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(cmax, o); cmax = (w > cmax) ? w : cmax; }
+        cmax = __builtin_amdgcn_readfirstlane(cmax < S ? cmax : S);
+        for (int s = 0; s < cmax; s++)
           if (s < cnt) one_source(s);
       }
     };
@@ -383,7 +405,7 @@ template <class Ker, class R, int MODE>
 __global__ void __launch_bounds__(kListWave) lists_kernel(const ListArgs<R> a) {
   using V = typename VecOf<R>::type;
   constexpr int NV = (Ker::NREC + VecOf<R>::N - 1) / VecOf<R>::N;
-  __shared__ V tile[kListTile * NV + 8];     // (+ 8: the packed items' slices are one word apart)
+  __shared__ V tile[kPackedTileWords(NV)];   // 64 records for the one-range items; the packed items' slices: 8 x (16 records + 1 word)
   using KC = typename Ker::template Consts<R>;
   __shared__ double kscratch[KC::LDS_DOUBLES > 0 ? KC::LDS_DOUBLES : 1];
   const KC K = make_consts<KC>(kscratch, a.ctx, MODE);
@@ -397,10 +419,10 @@ __global__ void __launch_bounds__(kListWave) lists_kernel(const ListArgs<R> a) {
   const ListItem it = a.items[a.xcd_first[xcd] + j];
   if (it.nranges < 0) {      // packed small target ranges
     const int cls = -1 - it.nranges;
-    if (cls == 0) lists_packed_item<Ker, R, MODE, 8, 1>(a, it, tile, K);
-    else if (cls == 1) lists_packed_item<Ker, R, MODE, 8, 2>(a, it, tile, K);
-    else if (cls == 2) lists_packed_item<Ker, R, MODE, 16, 2>(a, it, tile, K);
-    else lists_packed_item<Ker, R, MODE, 32, 2>(a, it, tile, K);
+    if (cls == 0) lists_packed_item<Ker, R, MODE, 8, 1, 2>(a, it, tile, K);
+    else if (cls == 1) lists_packed_item<Ker, R, MODE, 8, 2, 2>(a, it, tile, K);
+    else if (cls == 2) lists_packed_item<Ker, R, MODE, 16, 2, 2>(a, it, tile, K);
+    else lists_packed_item<Ker, R, MODE, 32, 2, 1>(a, it, tile, K);
     return;
   }
   if (it.nt > kListWave) lists_item<Ker, R, MODE, 2, false>(a, it, tile, K);
