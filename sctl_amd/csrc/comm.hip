@@ -18,6 +18,7 @@
 #include <sys/socket.h>
 #include <unistd.h>
 
+#include <cerrno>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -293,8 +294,11 @@ int sctl_amd_comm_create(int rank, int size, const char* master_addr, int master
       if (left_ms <= 0 || ::poll(&pf, 1, (int)left_ms) <= 0)
         return set_error(SCTL_AMD_ERR_PEER, "rendezvous: " + std::to_string(size - joined) + " rank(s) did not connect within 5 minutes");
       const int f = ::accept(c->listen_fd, nullptr, nullptr);
-      if (f < 0) continue;
-      timeval tv{10, 0};                       // a connection that says nothing within 10 s is not one of ours
+      if (f < 0) {                             // transient (the peer went away between poll and accept): try again; anything else (EMFILE, ...) will not
+        if (errno == EINTR || errno == EAGAIN || errno == EWOULDBLOCK || errno == ECONNABORTED) continue;   // mend itself by spinning until the deadline
+        return set_error(SCTL_AMD_ERR_HIP, std::string("rendezvous: accept() failed: ") + std::strerror(errno));
+      }
+      timeval tv{2, 0};                        // a connection that says nothing within 2 s is not one of ours (a member sends its hello at once)
       (void)setsockopt(f, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
       Hello h{};
       if (!recv_all(f, &h, sizeof h) || h.magic != kMagic || h.size != size || h.token != token || h.rank < 1 || h.rank >= size || c->fd[(size_t)h.rank] >= 0) {
