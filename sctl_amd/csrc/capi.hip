@@ -25,10 +25,10 @@ int comm_gather_to_device(sctl_amd_comm* c, const void* local, int64_t nbytes, v
 // centered.hip
 template <class R>
 hipError_t eval_centered(int kernel_id, int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* xn, const R* f, R* v_trg, double scale, int mode,
-                         int cus, hipStream_t st, bool presorted);
+                         int cus, hipStream_t st, bool presorted, int64_t density);
 void centered_plan(int64_t Nt, int64_t Ns, int cus, int src_bytes, int* T, int* splits, int64_t* chunk);
 int centered_pipe(int kernel_id, int real, int mode);
-int centered_targets_per_wave(int kernel_id, int real, int mode);
+int centered_targets_per_wave(int kernel_id, int real, int mode, int64_t density);
 hipError_t morton_order_device(int real, const void* d_x, int64_t n, void* d_sorted, uint32_t* d_perm, hipStream_t st);   // centered.hip
 namespace {
 
@@ -244,8 +244,10 @@ bool use_centered(const KernelEntry& k, int real, int64_t Nt, int64_t Ns, int64_
 }
 
 template <class R>
-int run_centered(const KernelEntry& k, int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* xn, const R* f, R* v, int mode, hipStream_t st, bool presorted) {
-  HIP_TRY(eval_centered<R>(k.id, Nt, Ns, xt, xs, xn, f, v, k.scale / k.acc_factor[mode], mode, cu_count(), st, presorted));
+int run_centered(const KernelEntry& k, int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* xn, const R* f, R* v, int mode, hipStream_t st, bool presorted,
+                 int64_t nt_whole) {
+  // density of the target set: the size of the set these targets were cut from as a compact slab (the whole set for a plain call)
+  HIP_TRY(eval_centered<R>(k.id, Nt, Ns, xt, xs, xn, f, v, k.scale / k.acc_factor[mode], mode, cu_count(), st, presorted, Nt > nt_whole ? Nt : nt_whole));
   g_pairs += Nt * Ns;
   g_flops += Nt * Ns * k.flops;
   return SCTL_AMD_OK;
@@ -258,7 +260,7 @@ int eval_device_t(const KernelEntry& k, int real, int64_t Nt, int64_t Ns, const 
   (void)hipGetLastError();                      // drop a stale error of an earlier, unrelated runtime call on this thread
   const Plan p = make_plan(k, real, Nt, Ns);
   const int mode = mode_for(real, digits);
-  if (use_centered(k, real, Nt, Ns, nt_whole, presorted)) return run_centered<R>(k, Nt, Ns, xt, xs, xn, f, v, mode, st, presorted);
+  if (use_centered(k, real, Nt, Ns, nt_whole, presorted)) return run_centered<R>(k, Nt, Ns, xt, xs, xn, f, v, mode, st, presorted, nt_whole);
   EvalArgs<R> a{};
   a.Nt = Nt; a.Ns = Ns; a.xt = xt; a.xs = xs; a.xn = xn; a.f = f; a.v_trg = v; a.partial = nullptr;
   a.chunk = p.chunk; a.scale = (R)(k.scale / k.acc_factor[mode]); a.ctx = make_ctx(k, ctx);   // pair() of this mode may accumulate a multiple (launch.hpp)
@@ -1277,7 +1279,7 @@ int sctl_amd_eval_plan(int kernel, int real, int64_t Nt, int64_t Ns, int64_t Nt_
     int T, splits;
     int64_t chunk;
     centered_plan(Nt, Ns, cu_count(), (real == SCTL_AMD_F64 ? 8 : 4) * (3 + k->nd + k->k0), &T, &splits, &chunk);
-    const int64_t per_wave = centered_targets_per_wave(k->id, real, mode_for(real, digits));   // 128, or 256 for the matrix-core double layer (centered.hip)
+    const int64_t per_wave = centered_targets_per_wave(k->id, real, mode_for(real, digits), Nt > Nt_whole ? Nt : Nt_whole);   // (centered.hip)
     (void)T;
     if (trg_per_lane) *trg_per_lane = (int)(per_wave / 64);
     if (src_splits) *src_splits = splits;

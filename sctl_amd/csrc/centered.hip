@@ -37,11 +37,13 @@ bool use_mfma_f32() {
 int centered_pipe(int kernel_id, int real, int mode) {
   return ((kernel_id == Laplace3D_FxU::ID || kernel_id == Laplace3D_DxU::ID) && real == 1 /* SCTL_AMD_F32 */ && mode == 0 && use_mfma_f32()) ? 2 : 1;
 }
-// Targets per wave (= per workgroup) of that path: 128 (two per lane) on the vector pipe, 256 = eight 32-column blocks for the matrix-core kernels, whose
-// per-tile staging (one or two contraction rows per source) is then shared by twice the pairs: double layer 745 -> 672 ms at 2^21; single layer 446 -> 426 ms
-// once it keeps three waves per SIMD at that size (centered_mfma_kernel.hpp).  A/B on one box, profiles/r03_ab_mfma_variants.txt, r03_ab_mfma_sl_occupancy.txt.
-// SCTL_AMD_MFMA_CB=4 / 8 overrides (A/B runs).
-int centered_targets_per_wave(int kernel_id, int real, int mode) {
+// Targets per wave (= per workgroup) of that path: 64 per target of a lane on the vector pipe (the policy's targets_per_lane); for the matrix-core kernels 256 = eight
+// 32-column blocks — the per-tile staging (one or two contraction rows per source) is shared by twice the pairs of the 128-target form — except for the single layer on a
+// SPARSE target set: below 2^20 targets in the domain (`density`: the size of the set the targets were cut from) the larger cluster of 256 targets makes too many sources
+// "near", and the 128-target form (120 registers, four waves per SIMD) wins.  A/B on one box, fp32 (tools/ab_mfma_cb_sizes.py, profiles/r04_ab_mfma_cb_sizes.txt), 256 vs 128
+// targets per wave: single layer 2^18 8.27 vs 7.75 ms, 2^19 29.2 vs 28.8, 2^20 111.4 vs 112.0, 2^21 427.4 vs 438.0; double layer 12.6 vs 13.6, 46.3 vs 50.8, 175.6 vs
+// 198.1, 679 vs 773 (256 everywhere).  SCTL_AMD_MFMA_CB=4 / 8 overrides (A/B runs, tests).
+int centered_targets_per_wave(int kernel_id, int real, int mode, int64_t density) {
   if (centered_pipe(kernel_id, real, mode) != 2) {
     if (kernel_id == Laplace3D_FxdU::ID) return 64 * CenteredFxdU<double>::targets_per_lane<double>();
     return 64 * (real == 0 /* SCTL_AMD_F64 */ ? CenteredFxU<double>::targets_per_lane<double>() : CenteredFxU<float>::targets_per_lane<float>());
@@ -50,14 +52,13 @@ int centered_targets_per_wave(int kernel_id, int real, int mode) {
     if (e[0] == '8') return 256;
     if (e[0] == '4') return 128;
   }
-  return 256;
+  return (kernel_id == Laplace3D_FxU::ID && density < ((int64_t)1 << 20)) ? 128 : 256;
 }
 namespace {
-template <class CP, class R, int MODE> void launch_centered(const EvalArgs<R>& a, dim3 grid, hipStream_t st) {
+template <class CP, class R, int MODE> void launch_centered(const EvalArgs<R>& a, dim3 grid, int per_wave, hipStream_t st) {
   if constexpr (std::is_same<R, float>::value && MODE == 0) {
-    if (use_mfma_f32()) {   // (the caller sized grid.x with centered_targets_per_wave)
+    if (use_mfma_f32()) {   // (the caller sized grid.x with per_wave = centered_targets_per_wave)
       constexpr bool DL = std::is_same<CP, CenteredDxU<float>>::value;
-      const int per_wave = centered_targets_per_wave(CP::Ker::ID, 1, 0);
       if (per_wave == 256) {
         if constexpr (DL) hipLaunchKernelGGL((centered_mfma_f32_kernel<true, 8>), grid, dim3(kWaveBlock), 0, st, a);
         else hipLaunchKernelGGL(centered_mfma_fxu256_f32_kernel, grid, dim3(kWaveBlock), 0, st, a);
@@ -98,7 +99,7 @@ void centered_plan(int64_t Nt, int64_t Ns, int cus, int src_bytes, int* T, int* 
 
 template <class CP, class R>
 hipError_t eval_centered_t(int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* xn, const R* f, R* v_trg, double scale_d, int mode, int cus,
-                           hipStream_t st, bool presorted) {
+                           hipStream_t st, bool presorted, int64_t density) {
   const R scale = (R)scale_d;
   constexpr int K1 = CP::Ker::K1;
   int T, splits;
@@ -115,11 +116,11 @@ hipError_t eval_centered_t(int64_t Nt, int64_t Ns, const R* xt, const R* xs, con
     a.Nt = Nt; a.Ns = Ns; a.xt = xt; a.xs = xs; a.xn = xn; a.f = f; a.v_trg = v_trg; a.partial = partial;
     a.chunk = chunk; a.scale = scale;
     a.ctx.v[0] = kNearFactor2;
-    const int64_t per_wave = centered_targets_per_wave(CP::Ker::ID, sizeof(R) == 8 ? 0 : 1, mode);
+    const int64_t per_wave = centered_targets_per_wave(CP::Ker::ID, sizeof(R) == 8 ? 0 : 1, mode, density);
     const dim3 grid((unsigned)((Nt + per_wave - 1) / per_wave), (unsigned)splits);
-    if (mode == 0) launch_centered<CP, R, 0>(a, grid, st);
-    else if (mode == 1) launch_centered<CP, R, 1>(a, grid, st);
-    else launch_centered<CP, R, (sizeof(R) == 8 ? 2 : 1)>(a, grid, st);
+    if (mode == 0) launch_centered<CP, R, 0>(a, grid, (int)per_wave, st);
+    else if (mode == 1) launch_centered<CP, R, 1>(a, grid, (int)per_wave, st);
+    else launch_centered<CP, R, (sizeof(R) == 8 ? 2 : 1)>(a, grid, (int)per_wave, st);
     CENTERED_TRY(hipGetLastError());
     if (splits > 1)
       hipLaunchKernelGGL((reduce_splits_kernel<R>), dim3((unsigned)((Nt * K1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, v_trg, (const R*)partial, Nt * K1, splits, scale);
@@ -156,11 +157,11 @@ hipError_t eval_centered_t(int64_t Nt, int64_t Ns, const R* xt, const R* xs, con
   a.chunk = chunk; a.scale = scale;
   a.ctx.v[0] = kNearFactor2;
   a.partial = partial;
-  const int64_t per_wave = centered_targets_per_wave(CP::Ker::ID, sizeof(R) == 8 ? 0 : 1, mode);
+  const int64_t per_wave = centered_targets_per_wave(CP::Ker::ID, sizeof(R) == 8 ? 0 : 1, mode, density);
   const dim3 grid((unsigned)((Nt + per_wave - 1) / per_wave), (unsigned)splits);
-  if (mode == 0) launch_centered<CP, R, 0>(a, grid, st);
-  else if (mode == 1) launch_centered<CP, R, 1>(a, grid, st);
-  else launch_centered<CP, R, (sizeof(R) == 8 ? 2 : 1)>(a, grid, st);
+  if (mode == 0) launch_centered<CP, R, 0>(a, grid, (int)per_wave, st);
+  else if (mode == 1) launch_centered<CP, R, 1>(a, grid, (int)per_wave, st);
+  else launch_centered<CP, R, (sizeof(R) == 8 ? 2 : 1)>(a, grid, (int)per_wave, st);
   CENTERED_TRY(hipGetLastError());
   if (splits > 1)
     hipLaunchKernelGGL((reduce_splits_kernel<R>), dim3((unsigned)((Nt * K1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, outs, (const R*)a.partial, Nt * K1, splits, scale);
@@ -199,14 +200,14 @@ hipError_t morton_order_device(int real, const void* d_x, int64_t n, void* d_sor
 // kernel id -> policy
 template <class R>
 hipError_t eval_centered(int kernel_id, int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* xn, const R* f, R* v_trg, double scale, int mode, int cus,
-                         hipStream_t st, bool presorted) {
-  if (kernel_id == Laplace3D_DxU::ID) return eval_centered_t<CenteredDxU<R>, R>(Nt, Ns, xt, xs, xn, f, v_trg, scale, mode, cus, st, presorted);
+                         hipStream_t st, bool presorted, int64_t density) {
+  if (kernel_id == Laplace3D_DxU::ID) return eval_centered_t<CenteredDxU<R>, R>(Nt, Ns, xt, xs, xn, f, v_trg, scale, mode, cus, st, presorted, density);
   if constexpr (std::is_same<R, double>::value) {   // vector outputs: fp64 (capi.hip: has_centered_path)
-    if (kernel_id == Laplace3D_FxdU::ID) return eval_centered_t<CenteredFxdU<R>, R>(Nt, Ns, xt, xs, xn, f, v_trg, scale, mode, cus, st, presorted);
+    if (kernel_id == Laplace3D_FxdU::ID) return eval_centered_t<CenteredFxdU<R>, R>(Nt, Ns, xt, xs, xn, f, v_trg, scale, mode, cus, st, presorted, density);
   }
-  return eval_centered_t<CenteredFxU<R>, R>(Nt, Ns, xt, xs, xn, f, v_trg, scale, mode, cus, st, presorted);
+  return eval_centered_t<CenteredFxU<R>, R>(Nt, Ns, xt, xs, xn, f, v_trg, scale, mode, cus, st, presorted, density);
 }
-template hipError_t eval_centered<double>(int, int64_t, int64_t, const double*, const double*, const double*, const double*, double*, double, int, int, hipStream_t, bool);
-template hipError_t eval_centered<float>(int, int64_t, int64_t, const float*, const float*, const float*, const float*, float*, double, int, int, hipStream_t, bool);
+template hipError_t eval_centered<double>(int, int64_t, int64_t, const double*, const double*, const double*, const double*, double*, double, int, int, hipStream_t, bool, int64_t);
+template hipError_t eval_centered<float>(int, int64_t, int64_t, const float*, const float*, const float*, const float*, float*, double, int, int, hipStream_t, bool, int64_t);
 
 }  // namespace sctl_amd
