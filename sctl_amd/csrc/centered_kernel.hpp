@@ -251,7 +251,8 @@ template <class R> struct CenteredFxdU : ExtraWords<R, 4> {
   using Ker = Laplace3D_FxdU;
   using Extra = typename ExtraWords<R, 4>::Extra;
   static constexpr int XW = 4, NF = 4, NEAR_CAP = 128;
-  // three targets per lane: a far record is four 16-byte words, so with two targets the loop is close to the LDS read rate, and four cost the registers of a third
+  // three targets per lane: a far record is four 16-byte words — with two targets 2 ds_read_b128 per pair, ~8 of the ~18 cycles per CU a wave-pair's arithmetic
+  // takes (a wave64 ds_read_b128 costs ~4.3 cycles per CU: tools/ubench/lds_multi_address.hip) — and four targets cost the registers of a third
   // wave per SIMD; against the exact kernel, one box: T = 2 +2.2 .. 2.5 %, T = 3 +4.3 .. 4.6 %, T = 4 +3.2 .. 4.1 % (2^18 and 2^20, profiles/r04_ab_centered_vec.txt)
   template <class RR> static constexpr int targets_per_lane() { return 3; }
   template <int MODE> static __device__ __forceinline__ void put_extra(R* base, int q, const R (&p)[3], const R*, const R* f) {
