@@ -81,7 +81,7 @@ template <class CP, class R, int MODE> void launch_centered(const EvalArgs<R>& a
 // 4 MB L2 of the XCD that owns the split (centered_kernel.hpp), i.e. <= 2 MB: at 2^23 fp32 sources in 2 splits every wave streamed 64 MB per
 // split through a 4 MB cache and the launch pulled 3.66 TB through the fabric (13 600 x the algorithmic bytes; PMC, profiles/r02_laplace_sl_f32_*).
 void centered_plan(int64_t Nt, int64_t Ns, int cus, int src_bytes, int* T, int* splits, int64_t* chunk) {
-  *T = 2;   // one target per lane is LDS-bound (3 LDS reads per pair): 498 ms vs 465 ms at 2^20
+  *T = 2;   // (the split rule was sized for 128 targets per wave; one target per lane measured 498 ms against 465 ms at 2^20, round 1)
   const int64_t wg_x = (Nt + kWaveBlock * 2 - 1) / (kWaveBlock * 2);
   const int64_t want = (int64_t)cus * 16 * 32;
   const int64_t ntile = (Ns + kWaveTile - 1) / kWaveTile;
