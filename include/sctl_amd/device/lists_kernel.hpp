@@ -274,33 +274,44 @@ __device__ __forceinline__ void lists_packed_item(const ListArgs<R>& a, const Li
     for (int k = 0; k < K0; k++) sf[u][k] = 0;
   }
   // The sources of a step are fetched one step ahead, their INDICES two steps ahead: index -> coordinates is a chain of two memory latencies, and a step
-  // is short.  Lane i of a group holds sources u P + i, u < SPL, of the step's S.  idx_next: its sources of the step after the one being gathered (-1: none).
+  // is short.  Lane i of a group holds sources u P + i, u < SPL, of the step's S.  idx_next: its sources of the step after the one being gathered (kNone: none).
+  // Everything here is 32-bit: the plan packs small ranges only while every source array is under 4 GB (lists.hip), so a source's byte offset fits an unsigned
+  // 32-bit register and its loads take the (scalar base, 32-bit lane offset) form — the 64-bit per-lane address arithmetic was a third of a step's bookkeeping.
+  constexpr uint32_t kNone = 0xffffffffu;
+  const uint32_t own_lo = (uint32_t)pg.t0, own_n = self ? (uint32_t)pg.nt : 0u;   // (own points exist only when the sources ARE the targets)
+  const uint32_t* const flat_g = a.flat + pg.flat_off;
   bool own = false;    // a source this lane holds for the coming step is one of its group's targets
-  int64_t idx_next[SPL];
+  uint32_t idx_next[SPL];
   auto load_idx = [&](int step) {
 #pragma unroll
     for (int u = 0; u < SPL; u++) {
       const int q = step * S + u * P + i;
-      idx_next[u] = (q < nsrc) ? (int64_t)a.flat[pg.flat_off + q] : (int64_t)-1;
+      idx_next[u] = (q < nsrc) ? flat_g[q] : kNone;
     }
   };
   if (nsteps > 0) load_idx(0);
+  auto at = [](const R* base, uint32_t byte_off) -> const R* { return (const R*)((const char*)base + byte_off); };
   auto fetch = [&](int step) {
-    int64_t src[SPL];
+    uint32_t src[SPL];
 #pragma unroll
     for (int u = 0; u < SPL; u++) src[u] = idx_next[u];
     if (step + 1 < nsteps) load_idx(step + 1);
     own = false;
 #pragma unroll
     for (int u = 0; u < SPL; u++) {
-      if (src[u] >= 0) {
-        own = own || (self && src[u] >= pg.t0 && src[u] < pg.t0 + pg.nt);
+      if (src[u] != kNone) {
+        own = own || (src[u] - own_lo < own_n);
+        const R* const px = at(a.xs, src[u] * (uint32_t)(3 * sizeof(R)));
 #pragma unroll
-        for (int k = 0; k < 3; k++) sx[u][k] = a.xs[src[u] * 3 + k];
+        for (int k = 0; k < 3; k++) sx[u][k] = px[k];
+        if (ND > 0) {
+          const R* const pn = at(a.xn, src[u] * (uint32_t)(ND * sizeof(R)));
 #pragma unroll
-        for (int k = 0; k < ND; k++) sn[u][k] = a.xn[src[u] * ND + k];
+          for (int k = 0; k < ND; k++) sn[u][k] = pn[k];
+        }
+        const R* const pf = at(a.f, src[u] * (uint32_t)(K0 * sizeof(R)));
 #pragma unroll
-        for (int k = 0; k < K0; k++) sf[u][k] = a.f[src[u] * K0 + k];
+        for (int k = 0; k < K0; k++) sf[u][k] = pf[k];
       }
     }
   };

@@ -92,7 +92,9 @@ int sctl_amd_lists_create(int kernel, int real, int device, int64_t nlists, cons
   std::vector<uint32_t> flat;
   // The packed form keeps one 32-bit source index per (small target range, source): it is used while that list stays below 2^30 entries (4 GB) and the
   // sources can be indexed with 32 bits; SCTL_AMD_LISTS_PACK=0 keeps every range on the one-range-per-wave items (A/B runs, tests of that path)
-  bool pack_small = Ns <= (int64_t)UINT32_MAX;
+  // (and while every source array stays under 4 GB: the packed items address a source by a 32-bit byte offset)
+  const int64_t widest = (int64_t)(real == SCTL_AMD_F64 ? 8 : 4) * std::max<int64_t>(3, std::max<int64_t>(k->nd, k->k0));
+  bool pack_small = Ns <= (int64_t)UINT32_MAX / widest;
   int64_t pack_upto = kPackUpTo;
   if (const char* e = std::getenv("SCTL_AMD_LISTS_PACK")) pack_upto = std::min<int64_t>(64, std::atoi(e));   // (0: off; 8 / 16 / 32 / 64: the largest packed range)
   pack_small = pack_small && pack_upto > 0;
