@@ -218,10 +218,11 @@ namespace {
 // Tile-centred fast path (centered_kernel.hpp): Laplace single layer (fp64 and fp32) on problems large enough to amortise the
 // Morton sort of the targets.  SCTL_AMD_CENTERED=0 in the environment forces the exact kernel (used for A/B checks).
 // nt_whole: size of the target set the Nt targets were cut from as a spatially compact slab (= Nt for a whole set).
-// Laplace single and double layer (fp64 and fp32) and, fp64 only, the gradient of the single layer (round 4: far sources summed as moments)
+// Laplace single and double layer (fp64 and fp32) and, fp64 only, the gradient of the single layer and the Stokes velocity + pressure kernel (round 4: far sources
+// summed as moments)
 bool has_centered_path(const KernelEntry& k, int real) {
   if (k.id == SCTL_AMD_LAPLACE3D_FXU || k.id == SCTL_AMD_LAPLACE3D_DXU) return true;
-  return real == SCTL_AMD_F64 && k.id == SCTL_AMD_LAPLACE3D_FXDU;
+  return real == SCTL_AMD_F64 && (k.id == SCTL_AMD_LAPLACE3D_FXDU || k.id == SCTL_AMD_STOKES3D_FXUP);
 }
 constexpr int64_t kPresortMinTargets = 1 << 17;   // sctl_amd_op_* keeps the targets of such kernels in Morton order from this size on
 

@@ -46,6 +46,7 @@ int centered_pipe(int kernel_id, int real, int mode) {
 int centered_targets_per_wave(int kernel_id, int real, int mode, int64_t density) {
   if (centered_pipe(kernel_id, real, mode) != 2) {
     if (kernel_id == Laplace3D_FxdU::ID) return 64 * CenteredFxdU<double>::targets_per_lane<double>();
+    if (kernel_id == Stokes3D_FxUP::ID) return 64 * CenteredStokeslet<double, Stokes3D_FxUP>::targets_per_lane<double>();
     return 64 * (real == 0 /* SCTL_AMD_F64 */ ? CenteredFxU<double>::targets_per_lane<double>() : CenteredFxU<float>::targets_per_lane<float>());
   }
   if (const char* e = std::getenv("SCTL_AMD_MFMA_CB")) {
@@ -204,6 +205,7 @@ hipError_t eval_centered(int kernel_id, int64_t Nt, int64_t Ns, const R* xt, con
   if (kernel_id == Laplace3D_DxU::ID) return eval_centered_t<CenteredDxU<R>, R>(Nt, Ns, xt, xs, xn, f, v_trg, scale, mode, cus, st, presorted, density);
   if constexpr (std::is_same<R, double>::value) {   // vector outputs: fp64 (capi.hip: has_centered_path)
     if (kernel_id == Laplace3D_FxdU::ID) return eval_centered_t<CenteredFxdU<R>, R>(Nt, Ns, xt, xs, xn, f, v_trg, scale, mode, cus, st, presorted, density);
+    if (kernel_id == Stokes3D_FxUP::ID) return eval_centered_t<CenteredStokeslet<R, Stokes3D_FxUP>, R>(Nt, Ns, xt, xs, xn, f, v_trg, scale, mode, cus, st, presorted, density);
   }
   return eval_centered_t<CenteredFxU<R>, R>(Nt, Ns, xt, xs, xn, f, v_trg, scale, mode, cus, st, presorted, density);
 }

@@ -246,7 +246,8 @@ template <class R, int XW> struct ExtraWords {
 };
 // gradient of the single layer, u_j = sum_s f_s (x_t - x_s)_j / r^3 (kernel_functions.hpp:53-72): with A = f / r^3 the far sources give
 // u_j = x_t'_j S0 - S_j, S0 = sum A, S_j = sum A x_s'_j; the record carries {f, f x', f y', f z'}, so a far pair is the 4-instruction distance, the
-// reciprocal cube and FOUR accumulations: 17 issue slots where the exact pair has 19 (3 differences + 3 for r^2, one product f / r^3, 3 accumulations)
+// reciprocal cube and FOUR accumulations: 13 fp64 instructions + v_rsq_f64 (= 4 more slots) where the exact pair has 15 (3 differences + 3 for r^2, one product
+// f / r^3, 3 accumulations; tools/isa_loop_counts.py)
 template <class R> struct CenteredFxdU : ExtraWords<R, 4> {
   using Ker = Laplace3D_FxdU;
   using Extra = typename ExtraWords<R, 4>::Extra;
@@ -273,6 +274,46 @@ template <class R> struct CenteredFxdU : ExtraWords<R, 4> {
   template <int MODE> static __device__ __forceinline__ void finish(R (&out)[3], const R (&far)[NF], const R (&near)[3], const R (&m2x)[3]) {
 #pragma unroll
     for (int k = 0; k < 3; k++) out[k] = near[k] + fma_(R(-0.5) * m2x[k], far[0], -far[1 + k]);
+  }
+};
+// Stokeslet family (kernel_functions.hpp:74-95, 148-198): u_j = sum_s (f_j + r_j (r.f) / r^2) / r, with r = x_t' - x_s'.  With y = C / r, t = C^2 (r.f) / r^2
+// and w_j = C^2 f_j - t x_s'_j a far pair adds y w_j to S_j and t y to S_c, and u_j = S_j + x_t'_j S_c: FOUR sums per target where splitting the three terms would
+// take seven.  r.f comes as for the double layer, m2x . (-f/2) - x_s'.f, so the record carries {-f/2, -x_s'.f} for the dot product and C^2 f beside it (as the exact
+// kernel's record does): 4 (distance) + rsq + 4 (cubic step) + 3 (dot) + 2 (t) + 1 (S_c) + 6 = 20 fp64 instructions + v_rsq_f64 where the exact pair has 21 + v_rsq_f64
+// (3 differences and 3 for r^2; its speculative tile loop carries no mask) — ONE instruction of 25 slots' worth, which the near pairs eat: for the Stokeslet itself and for
+// Stokes3D_FSxU the path measures -1.4 .. +2.4 % against the exact kernel and is NOT used (profiles/r04_ab_centered_stokeslet.txt; PMC: 21.8 against 22.3 VALU instructions
+// per wave-pair, both kernels' vector pipe 90-94 % busy).  S_c is the PRESSURE of Stokes3D_FxUP as it stands, where the exact pair needs two more instructions for it:
+// that kernel takes this path, +6.3 % at 2^18, +7.4 % at 2^20.  (Stokes3D_FSxU would add its fourth density to the dot product's constant.)
+template <class R, class KER> struct CenteredStokeslet : ExtraWords<R, 8> {
+  using Ker = KER;
+  using Extra = typename ExtraWords<R, 8>::Extra;
+  static constexpr int XW = 8, NF = 4, NEAR_CAP = 64;   // (a near record is six 16-byte words: 128 pending ones would leave two waves per SIMD)
+  static_assert(KER::K0 == 3 || KER::K0 == 4, "three force components, optionally a source/sink strength");
+  static_assert(KER::K1 == 3 || KER::K1 == 4, "velocity, optionally the pressure");
+  template <class RR> static constexpr int targets_per_lane() { return 4; }   // six LDS words per far source: T = 2 / 3 / 4 measured 834 / 826 / 808 ms (Stokeslet, 2^20)
+  template <int MODE> static __device__ __forceinline__ void put_extra(R* base, int q, const R (&p)[3], const R*, const R* f) {
+    const R c2 = R(rsqrt_scaled_c2(MODE));
+    R g3 = -(p[0] * f[0] + p[1] * f[1] + p[2] * f[2]);
+    if constexpr (KER::K0 == 4) g3 += f[3];
+    Extra e{{R(-0.5) * f[0], R(-0.5) * f[1], R(-0.5) * f[2], g3, c2 * f[0], c2 * f[1], c2 * f[2], R(0)}};
+    ExtraWords<R, 8>::store_extra(base, q, e);
+  }
+  template <int MODE, int T, class KC> static __device__ __forceinline__ void far_pairs(R (&acc)[T][NF], const FarTargets<R, T>& tg, const R (&b)[4], const Extra& e,
+                                                                                          const KC& K) {
+#pragma unroll
+    for (int j = 0; j < T; j++) {
+      const R r2 = fma_(tg.m2x[j][0], b[0], fma_(tg.m2x[j][1], b[1], fma_(tg.m2x[j][2], b[2], tg.tt[j] + b[3])));
+      const R y = rsqrt_scaled<MODE, false>(r2, K.rsq);                                                              // C / r, as Ker::pair
+      const R t = fma_(tg.m2x[j][0], e.g[0], fma_(tg.m2x[j][1], e.g[1], fma_(tg.m2x[j][2], e.g[2], e.g[3]))) * (y * y);   // C^2 (r.f) / r^2
+      acc[j][3] = fma_(t, y, acc[j][3]);
+#pragma unroll
+      for (int k = 0; k < 3; k++) acc[j][k] = fma_(y, fma_(-t, b[k], e.g[4 + k]), acc[j][k]);
+    }
+  }
+  template <int MODE> static __device__ __forceinline__ void finish(R (&out)[KER::K1], const R (&far)[NF], const R (&near)[KER::K1], const R (&m2x)[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) out[k] = near[k] + fma_(R(-0.5) * m2x[k], far[3], far[k]);
+    if constexpr (KER::K1 == 4) out[3] = near[3] + far[3];
   }
 };
 // (The fused single + double layer kernel, potential and gradient — BASELINE config 2 — was written the same way and is NOT kept: u = sum y (q' + w) and

@@ -101,6 +101,10 @@ def test_launch_planner():
         grad = sctl_amd.plan("Laplace3D-FxdU", 0, 1 << 20, 1 << 20)                           # the gradient: far sources as moments (round 4), three targets per lane, fp64 only
         assert grad["path"] == "tile-centred" and grad["trg_per_lane"] == 3 and grad["workspace_bytes"] == grad["src_splits"] * 3 * 8 << 20
         assert sctl_amd.plan("Laplace3D-FxdU", 1, 1 << 20, 1 << 20)["path"] == "exact"
+        up = sctl_amd.plan("Stokes3D-FxUP", 0, 1 << 20, 1 << 20)                              # velocity + pressure: the pressure IS one of the Stokeslet's four far moments
+        assert up["path"] == "tile-centred" and up["trg_per_lane"] == 4 and up["workspace_bytes"] == up["src_splits"] * 4 * 8 << 20
+        for name in ("Stokes3D-FxU", "Stokes3D-FSxU"):                                        # ... for the Stokeslet itself the moments save one instruction of 21: not taken
+            assert sctl_amd.plan(name, 0, 1 << 20, 1 << 20)["path"] == "exact"
         assert sctl_amd.plan("Laplace3D-FDxUdU", 0, 1 << 20, 1 << 20)["path"] == "exact"      # its centred form measured slower than the exact kernel
         # which units run the far pairs (sctl_amd_eval_pipe): the bf16 matrix cores only for fp32 scalar Laplace at the seed's accuracy
         if os.environ.get("SCTL_AMD_MFMA_F32") != "0":

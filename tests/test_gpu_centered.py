@@ -37,9 +37,9 @@ def _clouds(kind, rng):
 
 
 @pytest.mark.parametrize("kind", ["uniform", "clustered", "surface", "identical_targets", "offset"])
-@pytest.mark.parametrize("name", ["Laplace3D-FxU", "Laplace3D-DxU", "Laplace3D-FxdU"])
+@pytest.mark.parametrize("name", ["Laplace3D-FxU", "Laplace3D-DxU", "Laplace3D-FxdU", "Stokes3D-FxUP"])
 def test_centred_path_matches_oracle_and_exact_kernel(O, name, kind):
-    """(the gradient kernel, round 4: its far sources are summed as moments, x_t' sum A - sum A x_s'; fp64 only)"""
+    """(the gradient kernel and the Stokes velocity + pressure kernel, round 4: their far sources are summed as moments, x_t' sum A - sum A x_s'; fp64 only)"""
     import torch
     rng = np.random.default_rng(123)
     xt, xs = _clouds(kind, rng)
@@ -250,7 +250,7 @@ def test_centred_kernels_give_bit_identical_results_run_to_run(kind):
             if cb:
                 os.environ["SCTL_AMD_MFMA_CB"] = cb
             try:
-                for name in ("Laplace3D-FxU", "Laplace3D-DxU") + (("Laplace3D-FxdU",) if dt == np.float64 else ()):
+                for name in ("Laplace3D-FxU", "Laplace3D-DxU") + (("Laplace3D-FxdU", "Stokes3D-FxUP") if dt == np.float64 else ()):
                     pl = sctl_amd.plan(name, 1 if dt == np.float32 else 0, NT, NS)
                     want = 3 if name.endswith("FxdU") else per_lane
                     if dt == np.float32 and mfma == "1" and cb is None and name.endswith("FxU"):
@@ -258,7 +258,8 @@ def test_centred_kernels_give_bit_identical_results_run_to_run(kind):
                         assert sctl_amd.plan(name, 1, 1 << 20, NS)["trg_per_lane"] == 4 and sctl_amd.plan(name, 1, NT, NS, nt_whole=1 << 21)["trg_per_lane"] == 4
                     assert pl["path"] == "tile-centred" and pl["trg_per_lane"] == want, (pl, mfma, cb)
                     assert pl["pipe"].startswith("bf16 matrix cores") == (dt == np.float32 and mfma == "1"), pl
-                    runs = [sctl_amd.eval_device(name, d[0], d[1], d[2] if name.endswith("DxU") else None, d[3]).clone() for _ in range(6)]
+                    dens = d[3] if sctl_amd.kernel_info(name)["k0"] == 1 else d[2]       # (three density components: the array drawn for the normals)
+                    runs = [sctl_amd.eval_device(name, d[0], d[1], d[2] if name.endswith("DxU") else None, dens).clone() for _ in range(6)]
                     assert bool(torch.isfinite(runs[0]).all())
                     for r in runs[1:]:
                         assert int((r.view(bits) != runs[0].view(bits)).sum()) == 0, (name, dt.__name__, mfma, cb, kind)

@@ -86,7 +86,7 @@ def test_full_size_target_subset_against_the_reference(O, seed, name):
 
 
 @pytest.mark.parametrize("name,Nt,Ns", [("Stokes3D-FxU", 150001, 131075), ("Helmholtz3D-FxU", 70001, 300007), ("Laplace3D-FDxUdU", 33000, 600011),
-                                        ("Stokes3D-FxUP", 262147, 65601)])
+                                        ("Stokes3D-FSxU", 262147, 65601)])
 def test_ragged_sizes_under_the_l2_split_rule(O, name, Nt, Ns):
     """From 2^34 pairs on the planner cuts the sources into splits of <= 2 MB, in eights, each owned by one XCD (the kernel remaps its launch
     index to (tile, split)): ragged target and source counts — a last tile and a last split that are partly empty — against the oracle on a

@@ -1,4 +1,5 @@
-"""Tile-centred against exact path (SCTL_AMD_CENTERED=0) for the Laplace kernels with vector outputs (round 4), fp64, one box."""
+"""Tile-centred against exact path (SCTL_AMD_CENTERED=0) for kernels with vector outputs (round 4), fp64, one box.
+usage: ab_centered_vec.py [kernel names ...]   (default: the Laplace gradient; SCTL_AMD_LIB selects a scratch build of the library)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, sctl_amd
@@ -24,5 +25,5 @@ def run(name, N, reps, digits=-1):
     d = float((out['1'][1]-out['0'][1]).norm()/out['0'][1].norm())
     print("%-18s N=2^%d digits %3d  centred %9.2f ms (%5.1f %%, T=%d, %d splits)   exact %9.2f ms (%5.1f %%)   rel-L2 between them %.1e" % (name, N.bit_length()-1, digits,
           out['1'][0], 100*N*N*fl/(out['1'][0]*1e-3)/78.6e12, out['1'][2]['trg_per_lane'], out['1'][2]['src_splits'], out['0'][0], 100*N*N*fl/(out['0'][0]*1e-3)/78.6e12, d), flush=True)
-for name in ('Laplace3D-FxdU', 'Laplace3D-FDxUdU'):
+for name in (sys.argv[1:] or ['Laplace3D-FxdU']):
     run(name, 1 << 18, 5); run(name, 1 << 18, 5, 10); run(name, 1 << 20, 2); run(name, 1 << 20, 2, 10)

@@ -1,11 +1,12 @@
 """Time one kernel at one size on the GPU: python tools/time_one.py <kernel> <log2 N | log2Nt,log2Ns> <f64|f32> [digits]
 (SCTL_AMD_LIB selects another build of the library, SCTL_AMD_CENTERED=0 disables the tile-centred Laplace path)."""
+import os
 import sys
 
 import numpy as np
 import torch
 
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sctl_amd  # noqa: E402
 
 name, logs, dts = sys.argv[1], sys.argv[2], sys.argv[3]
