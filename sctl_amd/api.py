@@ -198,7 +198,7 @@ def plan(name, real, Nt, Ns, digits=-1, nt_whole=0):
     path = lib().sctl_amd_eval_path(kernel_id(name), real, Nt, Ns, nt_whole)
     pipe = lib().sctl_amd_eval_pipe(kernel_id(name), real, Nt, Ns, nt_whole, digits)
     return dict(trg_per_lane=t.value, src_splits=s.value, workgroups=wg.value, workspace_bytes=ws.value,
-                path="tile-centred" if path == 1 else "exact",
+                path="tile-centred" if (path == 1 and pipe >= 1) else "exact",     # (eval_path answers for the default accuracy, eval_pipe for `digits`)
                 pipe="bf16 matrix cores (r^2) + vector pipe (rsqrt, accumulate)" if pipe == 2 else "vector pipe")
 
 

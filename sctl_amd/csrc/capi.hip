@@ -220,16 +220,20 @@ namespace {
 // nt_whole: size of the target set the Nt targets were cut from as a spatially compact slab (= Nt for a whole set).
 // Laplace single and double layer (fp64 and fp32) and, fp64 only, the gradient of the single layer and the Stokes velocity + pressure kernel (round 4: far sources
 // summed as moments)
-bool has_centered_path(const KernelEntry& k, int real) {
+// mode < 0: the mode of the default accuracy request (what an operator handle sorts its targets for)
+bool has_centered_path(const KernelEntry& k, int real, int mode = -1) {
+  if (mode < 0) mode = mode_for(real, -1);
   if (k.id == SCTL_AMD_LAPLACE3D_FXU || k.id == SCTL_AMD_LAPLACE3D_DXU) return true;
-  return real == SCTL_AMD_F64 && (k.id == SCTL_AMD_LAPLACE3D_FXDU || k.id == SCTL_AMD_STOKES3D_FXUP);
+  if (real == SCTL_AMD_F64) return k.id == SCTL_AMD_LAPLACE3D_FXDU || k.id == SCTL_AMD_STOKES3D_FXUP;
+  // fp32: the Stokeslet family at the seed's accuracy, r2 and r.f on the matrix cores (centered_mfma_kernel.hpp); more digits: the exact kernel
+  return (k.id == SCTL_AMD_STOKES3D_FXU || k.id == SCTL_AMD_STOKES3D_FSXU || k.id == SCTL_AMD_STOKES3D_FXUP) && centered_pipe(k.id, real, mode) == 2;
 }
 constexpr int64_t kPresortMinTargets = 1 << 17;   // sctl_amd_op_* keeps the targets of such kernels in Morton order from this size on
 
-bool use_centered(const KernelEntry& k, int real, int64_t Nt, int64_t Ns, int64_t nt_whole = 0, bool presorted = false) {
+bool use_centered(const KernelEntry& k, int real, int64_t Nt, int64_t Ns, int64_t nt_whole = 0, bool presorted = false, int mode = -1) {
   const char* e = std::getenv("SCTL_AMD_CENTERED");   // read per call so that a test can A/B both paths in one process
   const bool enabled = !(e && e[0] == '0'), forced = (e && e[0] == '1');
-  if (!enabled || !has_centered_path(k, real) || Nt >= (int64_t(1) << 32)) return false;
+  if (!enabled || !has_centered_path(k, real, mode) || Nt >= (int64_t(1) << 32)) return false;
   if (forced) return Nt >= 128 && Ns >= 64;
   // (targets already in Morton order — `presorted`, no per-call sort/gather/scatter — do not move the crossover: at 2^17 x 2^17 the
   // centred kernel itself is level with the exact one, 8.14 vs 8.05 ms, because ~10 % of the sources are near; tools/presorted_threshold.py)
@@ -261,7 +265,7 @@ int eval_device_t(const KernelEntry& k, int real, int64_t Nt, int64_t Ns, const 
   (void)hipGetLastError();                      // drop a stale error of an earlier, unrelated runtime call on this thread
   const Plan p = make_plan(k, real, Nt, Ns);
   const int mode = mode_for(real, digits);
-  if (use_centered(k, real, Nt, Ns, nt_whole, presorted)) return run_centered<R>(k, Nt, Ns, xt, xs, xn, f, v, mode, st, presorted, nt_whole);
+  if (use_centered(k, real, Nt, Ns, nt_whole, presorted, mode)) return run_centered<R>(k, Nt, Ns, xt, xs, xn, f, v, mode, st, presorted, nt_whole);
   EvalArgs<R> a{};
   a.Nt = Nt; a.Ns = Ns; a.xt = xt; a.xs = xs; a.xn = xn; a.f = f; a.v_trg = v; a.partial = nullptr;
   a.chunk = p.chunk; a.scale = (R)(k.scale / k.acc_factor[mode]); a.ctx = make_ctx(k, ctx);   // pair() of this mode may accumulate a multiple (launch.hpp)
@@ -1276,7 +1280,7 @@ int sctl_amd_eval_plan(int kernel, int real, int64_t Nt, int64_t Ns, int64_t Nt_
   if (!k) return fail(SCTL_AMD_ERR_UNKNOWN_KERNEL, "unknown kernel id");
   if (real != SCTL_AMD_F64 && real != SCTL_AMD_F32) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "real must be SCTL_AMD_F64 or SCTL_AMD_F32");
   if (Nt < 0 || Ns < 0) return fail(SCTL_AMD_ERR_BAD_ARGUMENT, "negative size");
-  if (use_centered(*k, real, Nt, Ns, Nt_whole)) {
+  if (use_centered(*k, real, Nt, Ns, Nt_whole, false, mode_for(real, digits))) {
     int T, splits;
     int64_t chunk;
     centered_plan(Nt, Ns, cu_count(), (real == SCTL_AMD_F64 ? 8 : 4) * (3 + k->nd + k->k0), &T, &splits, &chunk);
@@ -1305,8 +1309,10 @@ int sctl_amd_eval_path(int kernel, int real, int64_t Nt, int64_t Ns, int64_t Nt_
 
 int sctl_amd_eval_pipe(int kernel, int real, int64_t Nt, int64_t Ns, int64_t Nt_whole, int digits) {
   const int path = sctl_amd_eval_path(kernel, real, Nt, Ns, Nt_whole);
-  if (path <= 0) return path;
-  return centered_pipe(registry(kernel)->id, real, mode_for(real, digits));
+  if (path < 0) return path;
+  const KernelEntry* k = registry(kernel);
+  if (!use_centered(*k, real, Nt, Ns, Nt_whole, false, mode_for(real, digits))) return 0;   // (a kernel may have its tile-centred form at some accuracies only)
+  return centered_pipe(k->id, real, mode_for(real, digits));
 }
 
 }  // extern "C"

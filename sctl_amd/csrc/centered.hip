@@ -35,7 +35,9 @@ bool use_mfma_f32() {
 // 2 when the tile-centred path of (kernel, real, mode) takes its far distances from the bf16 matrix cores, 1 when it runs on the vector pipe alone
 // (what sctl_amd_eval_pipe reports; must say what launch_centered does)
 int centered_pipe(int kernel_id, int real, int mode) {
-  return ((kernel_id == Laplace3D_FxU::ID || kernel_id == Laplace3D_DxU::ID) && real == 1 /* SCTL_AMD_F32 */ && mode == 0 && use_mfma_f32()) ? 2 : 1;
+  const bool has = kernel_id == Laplace3D_FxU::ID || kernel_id == Laplace3D_DxU::ID || kernel_id == Stokes3D_FxU::ID || kernel_id == Stokes3D_FSxU::ID ||
+                   kernel_id == Stokes3D_FxUP::ID;   // (the Stokeslet family, round 4: r.f is a second contraction, as the double layer's numerator)
+  return (has && real == 1 /* SCTL_AMD_F32 */ && mode == 0 && use_mfma_f32()) ? 2 : 1;
 }
 // Targets per wave (= per workgroup) of that path: 64 per target of a lane on the vector pipe (the policy's targets_per_lane); for the matrix-core kernels 256 = eight
 // 32-column blocks — the per-tile staging (one or two contraction rows per source) is shared by twice the pairs of the 128-target form — except for the single layer on a
@@ -49,14 +51,22 @@ int centered_targets_per_wave(int kernel_id, int real, int mode, int64_t density
     if (kernel_id == Stokes3D_FxUP::ID) return 64 * CenteredStokeslet<double, Stokes3D_FxUP>::targets_per_lane<double>();
     return 64 * (real == 0 /* SCTL_AMD_F64 */ ? CenteredFxU<double>::targets_per_lane<double>() : CenteredFxU<float>::targets_per_lane<float>());
   }
-  if (const char* e = std::getenv("SCTL_AMD_MFMA_CB")) {
+  if (const char* e = (kernel_id == Laplace3D_FxU::ID || kernel_id == Laplace3D_DxU::ID) ? std::getenv("SCTL_AMD_MFMA_CB") : nullptr) {
     if (e[0] == '8') return 256;
     if (e[0] == '4') return 128;
   }
+  if (kernel_id != Laplace3D_FxU::ID && kernel_id != Laplace3D_DxU::ID) return 128;   // the Stokeslet family: four column blocks
   return (kernel_id == Laplace3D_FxU::ID && density < ((int64_t)1 << 20)) ? 128 : 256;
 }
 namespace {
+template <class CP> struct stokeslet_policy_kernel { using type = void; };
+template <class R, class KER> struct stokeslet_policy_kernel<CenteredStokeslet<R, KER>> { using type = KER; };
 template <class CP, class R, int MODE> void launch_centered(const EvalArgs<R>& a, dim3 grid, int per_wave, hipStream_t st) {
+  using SK = typename stokeslet_policy_kernel<CP>::type;
+  if constexpr (std::is_same<R, float>::value && !std::is_void<SK>::value) {   // fp32 Stokeslet family: the matrix-core kernel at the seed's accuracy, nothing else
+    if constexpr (MODE == 0) hipLaunchKernelGGL((centered_mfma_stokeslet_f32_kernel<SK>), grid, dim3(kWaveBlock), 0, st, a);   // (capi.hip asks for this path at MODE 0 only)
+    return;
+  } else {
   if constexpr (std::is_same<R, float>::value && MODE == 0) {
     if (use_mfma_f32()) {   // (the caller sized grid.x with per_wave = centered_targets_per_wave)
       constexpr bool DL = std::is_same<CP, CenteredDxU<float>>::value;
@@ -70,6 +80,7 @@ template <class CP, class R, int MODE> void launch_centered(const EvalArgs<R>& a
     }
   }
   hipLaunchKernelGGL((centered_kernel<CP, R, MODE, CP::template targets_per_lane<R>()>), grid, dim3(kWaveBlock), 0, st, a);
+  }
 }
 }  // namespace
 
@@ -205,6 +216,11 @@ hipError_t eval_centered(int kernel_id, int64_t Nt, int64_t Ns, const R* xt, con
   if (kernel_id == Laplace3D_DxU::ID) return eval_centered_t<CenteredDxU<R>, R>(Nt, Ns, xt, xs, xn, f, v_trg, scale, mode, cus, st, presorted, density);
   if constexpr (std::is_same<R, double>::value) {   // vector outputs: fp64 (capi.hip: has_centered_path)
     if (kernel_id == Laplace3D_FxdU::ID) return eval_centered_t<CenteredFxdU<R>, R>(Nt, Ns, xt, xs, xn, f, v_trg, scale, mode, cus, st, presorted, density);
+    if (kernel_id == Stokes3D_FxUP::ID) return eval_centered_t<CenteredStokeslet<R, Stokes3D_FxUP>, R>(Nt, Ns, xt, xs, xn, f, v_trg, scale, mode, cus, st, presorted, density);
+  }
+  if constexpr (std::is_same<R, float>::value) {    // fp32 Stokeslet family on the matrix cores (mode 0; capi.hip: has_centered_path)
+    if (kernel_id == Stokes3D_FxU::ID) return eval_centered_t<CenteredStokeslet<R, Stokes3D_FxU>, R>(Nt, Ns, xt, xs, xn, f, v_trg, scale, mode, cus, st, presorted, density);
+    if (kernel_id == Stokes3D_FSxU::ID) return eval_centered_t<CenteredStokeslet<R, Stokes3D_FSxU>, R>(Nt, Ns, xt, xs, xn, f, v_trg, scale, mode, cus, st, presorted, density);
     if (kernel_id == Stokes3D_FxUP::ID) return eval_centered_t<CenteredStokeslet<R, Stokes3D_FxUP>, R>(Nt, Ns, xt, xs, xn, f, v_trg, scale, mode, cus, st, presorted, density);
   }
   return eval_centered_t<CenteredFxU<R>, R>(Nt, Ns, xt, xs, xn, f, v_trg, scale, mode, cus, st, presorted, density);

@@ -383,6 +383,307 @@ template <bool DL, int CB, bool STEP> __device__ __forceinline__ void centered_m
   }
 }
 
+// ---- the Stokeslet family in fp32 (Stokes3D_FxU / _FSxU / _FxUP, kernel_functions.hpp:74-95, 148-198; round 4) --------------------------------------------------
+// u_j = sum_s (f_j + r_j (r.f) / r^2) / r.  r.f is a second contraction against the SAME B operand, exactly as the double layer's numerator (rows of -f/2 against
+// -2 x_t', -x_s'.f against the ones; Stokes3D_FSxU adds its source strength to that constant), so the matrix cores hand the vector pipe r2 and r.f of 32 x 32 pairs
+// and the pipe is left with v_rsq_f32, t = (r.f) y^2, c = t y and the FOUR moments of CenteredStokeslet (centered_kernel.hpp): S_c += c, S_j += y f_j - c x_s'_j,
+// u_j = S_j + x_t'_j S_c — seven packed instructions per two pairs.  f_j and x_s'_j belong to the lane's 16 source rows: kept in LDS component by component, four
+// consecutive rows per 16-byte read, re-read for every column block in two halves (all sixteen rows of six components at once would take 96 registers).
+// 128 targets per wave (four column blocks), two waves per SIMD.  Stokes3D_FxUP's pressure is S_c.  fp32, MODE 0 only.
+template <class KER, int CB> __device__ __forceinline__ void centered_mfma_stokeslet_f32_body(const EvalArgs<float>& a) {
+  using R = float;
+  using Ker = KER;
+  static_assert((Ker::K0 == 3 || Ker::K0 == 4) && (Ker::K1 == 3 || Ker::K1 == 4) && Ker::ND == 0, "the Stokeslet family");
+  constexpr int kColBlocks = CB, NQ = CB / 2, K0 = Ker::K0, K1 = Ker::K1;
+  using V = Rec4<R>::V;
+  constexpr int NEARW = (Ker::NREC + 3) / 4;
+  constexpr int RW = 9;                         // r2 row, r.f row, one word of padding
+  constexpr int kRowsCap = kWaveTile + kMfmaRows, kRows4 = kRowsCap / 4;
+  constexpr int kNear = 64;                     // pending near sources (three words each; with 128 the workgroup's LDS would leave one wave per SIMD)
+  __shared__ u32x4 farA[kRowsCap * RW];
+  __shared__ f32x4 farS4[6 * kRows4];           // f_0, f_1, f_2, x', y', z' of the far rows, one array per component
+  __shared__ V nearA[(kNear + 2) * NEARW];
+  float* const farS = (float*)farS4;
+
+  const int lane = threadIdx.x, m = lane & 31, h = lane >> 5;
+  unsigned tile_idx = blockIdx.x, split_idx = blockIdx.y;
+  if ((gridDim.y & 7u) == 0) {   // XCD k owns the splits [k gridDim.y / 8, (k + 1) gridDim.y / 8) for all tiles (centered_kernel.hpp)
+    const unsigned b = blockIdx.y * gridDim.x + blockIdx.x, xcd = b & 7u, j = b >> 3, per = gridDim.y >> 3;
+    tile_idx = j % gridDim.x;
+    split_idx = xcd * per + j / gridDim.x;
+  }
+  const int64_t tbase = (int64_t)tile_idx * (32 * CB);
+  const typename Ker::template Consts<R> K(nullptr);
+
+  R c[3];
+  u32x4 Bop[kColBlocks][2];
+  R rt2 = 0;
+  {
+    R xb[kColBlocks][3];
+    R lo[3] = {max_finite<R>(), max_finite<R>(), max_finite<R>()}, hi[3] = {-lo[0], -lo[0], -lo[0]};
+#pragma unroll
+    for (int cb = 0; cb < kColBlocks; cb++) {
+      int64_t t = tbase + cb * 32 + m;
+      if (t >= a.Nt) t = a.Nt - 1;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        xb[cb][k] = a.xt[t * 3 + k];
+        lo[k] = (xb[cb][k] < lo[k]) ? xb[cb][k] : lo[k];
+        hi[k] = (xb[cb][k] > hi[k]) ? xb[cb][k] : hi[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) c[k] = uniform_(R(0.5) * wave_min(lo[k]) + R(0.5) * wave_max(hi[k]));
+#pragma unroll
+    for (int cb = 0; cb < kColBlocks; cb++) {
+      const R p[3] = {xb[cb][0] - c[0], xb[cb][1] - c[1], xb[cb][2] - c[2]};
+      const R tt = len2(p);
+      rt2 = (tt > rt2) ? tt : rt2;
+      const u32x4 w[4] = {b_word(-2.0f * p[0]), b_word(-2.0f * p[1]), b_word(-2.0f * p[2]), b_tail(tt)};
+#pragma unroll
+      for (int step = 0; step < 2; step++) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) Bop[cb][step][i] = h ? w[2 * step + 1][i] : w[2 * step][i];
+      }
+    }
+  }
+  rt2 = uniform_(wave_max(rt2));
+  const R near_r2 = R(a.ctx.v[0]) * rt2;
+
+  f32x2 acc[kColBlocks][4];   // the four far moments of this half-wave's source rows, per column block: {even rows, odd rows}
+#pragma unroll
+  for (int cb = 0; cb < kColBlocks; cb++)
+#pragma unroll
+    for (int k = 0; k < 4; k++) acc[cb][k] = f32x2{0, 0};
+  R accn[NQ][K1];
+#pragma unroll
+  for (int q = 0; q < NQ; q++)
+#pragma unroll
+    for (int k = 0; k < K1; k++) accn[q][k] = 0;
+
+  const int64_t s_begin = (int64_t)split_idx * a.chunk;
+  const int64_t s_end = (s_begin + a.chunk < a.Ns) ? s_begin + a.chunk : a.Ns;
+  const int64_t len = (s_end > s_begin) ? s_end - s_begin : 0;
+  const int ntile = (int)((len + kWaveTile - 1) / kWaveTile);
+
+  R x[3] = {0, 0, 0}, f[K0];
+#pragma unroll
+  for (int k = 0; k < K0; k++) f[k] = 0;
+  auto load_source = [&](int it) {
+    const int64_t s = s_begin + (int64_t)it * kWaveTile + lane;
+    if (s < s_end) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) x[k] = a.xs[s * 3 + k];
+#pragma unroll
+      for (int k = 0; k < K0; k++) f[k] = a.f[s * K0 + k];
+    }
+  };
+  if (ntile > 0) load_source(0);
+
+  const R far_off = uniform_(R(1.0e3) * (R(1) + sqrt_(rt2)));
+  auto put_near = [&](int q, const R (&xq)[3], const R (&fq)[K0]) {
+    R rec[4 * NEARW] = {};
+    const R nq[3] = {0, 0, 0};
+    pack_record<Ker, R, 0>(rec, xq, nq, fq);
+#pragma unroll
+    for (int g = 0; g < NEARW; g++) Rec4<R>::put(nearA + q * NEARW + g, rec[4 * g], rec[4 * g + 1], rec[4 * g + 2], rec[4 * g + 3]);
+  };
+  int nn = 0;
+  auto flush_near = [&]() {
+    if (nn & 1) {
+      if (lane == 0) {
+        R cx = c[0], fo = far_off;
+        asm volatile("" : "+v"(cx), "+v"(fo));
+        const R xq[3] = {cx + fo, c[1], c[2]}, fq[K0] = {};
+        put_near(nn, xq, fq);
+      }
+      __syncthreads();
+    }
+    R xo[NQ][3];
+    int lo = lane;
+    asm volatile("" : "+v"(lo));
+    const int mo = lo & 31, ho = lo >> 5;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      int64_t t = tbase + (NQ * ho + q) * 32 + mo;
+      if (t >= a.Nt) t = a.Nt - 1;
+#pragma unroll
+      for (int k = 0; k < 3; k++) xo[q][k] = a.xt[t * 3 + k];
+    }
+    for (int s = 0; s < nn; s += 2) {
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        R w[4 * NEARW];
+#pragma unroll
+        for (int g = 0; g < NEARW; g++) {
+          R v[4];
+          Rec4<R>::get(nearA + (s + u) * NEARW + g, v);
+          w[4 * g] = v[0]; w[4 * g + 1] = v[1]; w[4 * g + 2] = v[2]; w[4 * g + 3] = v[3];
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+          const R d[3] = {xo[q][0] - w[0], xo[q][1] - w[1], xo[q][2] - w[2]};
+          Ker::template pair<R, 0, true>(accn[q], d, w, a.ctx, K);
+          __builtin_amdgcn_sched_barrier(0);   // one pair after the other, never interleaved: see centered_kernel.hpp (flush_near)
+        }
+      }
+    }
+    nn = 0;
+  };
+
+  auto stage_tile = [&](int it, int carry) -> int {
+    const int ns = (it == ntile - 1) ? (int)(len - (int64_t)it * kWaveTile) : kWaveTile;
+    const bool valid = lane < ns;
+    const R p[3] = {x[0] - c[0], x[1] - c[1], x[2] - c[2]};
+    const R ss = len2(p);
+    const bool is_far = valid && (ss > near_r2);
+    const bool is_near = valid && !is_far;
+    const unsigned long long bf = __ballot(is_far), bn = __ballot(is_near);
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int nfar = __popcll(bf), nnear = __popcll(bn);
+    __syncthreads();   // previous tile's far rows fully consumed
+    if (nn + nnear > kNear) {
+      flush_near();
+      __syncthreads();
+    }
+    if (is_far) {
+      const int q = carry + __popcll(bf & below);
+      u32x4* row = farA + q * RW;
+      row[0] = a_word(p[0]);
+      row[1] = a_word(p[1]);
+      row[2] = a_word(p[2]);
+      row[3] = a_tail(ss, true);
+      row[4] = a_word(R(-0.5) * f[0]);
+      row[5] = a_word(R(-0.5) * f[1]);
+      row[6] = a_word(R(-0.5) * f[2]);
+      R g3 = -(p[0] * f[0] + p[1] * f[1] + p[2] * f[2]);
+      if constexpr (K0 == 4) g3 += f[3];
+      row[7] = a_tail(g3, false);
+#pragma unroll
+      for (int k = 0; k < 3; k++) { farS[k * kRowsCap + q] = f[k]; farS[(3 + k) * kRowsCap + q] = p[k]; }
+    } else if (is_near) {
+      put_near(nn + __popcll(bn & below), x, f);
+    }
+    nn += nnear;
+    return nfar;
+  };
+  auto mfma = [](u32x4 A, u32x4 B, f32x16 C) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0); };
+  auto run_far = [&](int nrows) {
+    const f32x16 zero = {};
+    int lr = lane;
+    asm volatile("" : "+v"(lr));
+    const u32x4* const row0 = farA + (lr & 31) * RW + (lr >> 5);
+    const f32x4* const sc0 = farS4 + (lr >> 5);
+    for (int r0 = 0; r0 < nrows; r0 += kMfmaRows) {
+      const u32x4* row = row0 + r0 * RW;
+      const u32x4 A0 = row[0], A1 = row[2], G0 = row[4], G1 = row[6];
+      const f32x4* const sc = sc0 + (r0 >> 2);
+      f32x4 w[6][4];   // f_j and x_s'_j of this lane's sixteen rows 8 k + 4 h + {0..3}: read once per row block, used by every column block
+#pragma unroll
+      for (int comp = 0; comp < 6; comp++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) w[comp][k] = sc[comp * kRows4 + 2 * k];
+#pragma unroll
+      for (int cb = 0; cb < kColBlocks; cb++) {
+        f32x16 r2 = mfma(A1, Bop[cb][1], mfma(A0, Bop[cb][0], zero)), rn = mfma(G1, Bop[cb][1], mfma(G0, Bop[cb][0], zero));
+#pragma unroll
+        for (int v = 0; v < 16; v++) r2[v] = __builtin_amdgcn_rsqf(r2[v]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int v = 0; v < 16; v += 2) {
+          const int k = v >> 2, e = v & 3;
+          const f32x2 y = {r2[v], r2[v + 1]};
+          const f32x2 t = f32x2{rn[v], rn[v + 1]} * (y * y);
+          const f32x2 cc = t * y;
+          acc[cb][3] += cc;
+#pragma unroll
+          for (int j = 0; j < 3; j++) {
+            acc[cb][j] += y * f32x2{w[j][k][e], w[j][k][e + 1]};
+            acc[cb][j] -= cc * f32x2{w[3 + j][k][e], w[3 + j][k][e + 1]};
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      asm volatile("" ::"v"(A0), "v"(A1), "v"(G0), "v"(G1));   // operands stay untouched until the VALU work behind the last MFMA is done
+    }
+  };
+  auto put_null_far = [&](int q) {   // r2 = 1 + |x_t'|^2 > 0, zero numerator, zero density: contributes exactly 0
+    u32x4* row = farA + q * RW;
+    row[0] = row[1] = row[2] = u32x4{0, 0, 0, 0};
+    row[3] = a_tail(1.0f, true);
+    row[4] = row[5] = row[6] = row[7] = u32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 6; k++) farS[k * kRowsCap + q] = 0;
+  };
+
+  int carry = 0;
+  for (int it = 0; it < ntile; it++) {
+    const int n = carry + stage_tile(it, carry), nrows = n & ~(kMfmaRows - 1);
+    if (it + 1 < ntile) load_source(it + 1);
+    __syncthreads();
+    run_far(nrows);
+    carry = n - nrows;
+    if (nrows > 0 && lane < carry) {   // the leftovers to the front (one wave: its LDS operations complete in program order)
+      u32x4 w[RW - 1];
+      float sv[6];
+#pragma unroll
+      for (int i = 0; i < RW - 1; i++) w[i] = farA[(nrows + lane) * RW + i];
+#pragma unroll
+      for (int k = 0; k < 6; k++) sv[k] = farS[k * kRowsCap + nrows + lane];
+#pragma unroll
+      for (int i = 0; i < RW - 1; i++) farA[lane * RW + i] = w[i];
+#pragma unroll
+      for (int k = 0; k < 6; k++) farS[k * kRowsCap + lane] = sv[k];
+    }
+  }
+  __syncthreads();
+  if (carry > 0) {
+    if (lane < kMfmaRows - carry) put_null_far(carry + lane);
+    __syncthreads();
+    run_far(kMfmaRows);
+  }
+  __syncthreads();
+  flush_near();
+
+#pragma unroll
+  for (int cb = 0; cb < kColBlocks; cb++) asm volatile("" ::"v"(Bop[cb][0]), "v"(Bop[cb][1]));   // (as the Laplace kernels: every MFMA operand outlives the VALU work behind it)
+
+  int le = lane;
+  asm volatile("" : "+v"(le));
+  const int me = le & 31, he = le >> 5, partner = (le ^ 32) << 2;
+  R far[kColBlocks][4];
+#pragma unroll
+  for (int cb = 0; cb < kColBlocks; cb++)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const R half_sum = acc[cb][k][0] + acc[cb][k][1];
+      far[cb][k] = half_sum + __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(half_sum)));
+    }
+#pragma unroll
+  for (int q = 0; q < NQ; q++) {
+    const int64_t t = tbase + (NQ * he + q) * 32 + me;
+    int64_t tc = (t < a.Nt) ? t : a.Nt - 1;
+    R out[K1];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const R xtp = a.xt[tc * 3 + k] - c[k];   // x_t' (re-read: an L2 hit once per kernel instead of 12 registers for all of it)
+      const R sk = he ? far[NQ + q][k] : far[q][k], scn = he ? far[NQ + q][3] : far[q][3];
+      out[k] = accn[q][k] + fma_(xtp, scn, sk);
+    }
+    if constexpr (K1 == 4) out[3] = accn[q][3] + (he ? far[NQ + q][3] : far[q][3]);
+    if (t < a.Nt) {
+#pragma unroll
+      for (int k = 0; k < K1; k++) {
+        if (gridDim.y == 1) a.v_trg[t * K1 + k] += out[k] * a.scale;
+        else a.partial[((int64_t)split_idx * a.Nt + t) * K1 + k] = out[k];
+      }
+    }
+  }
+}
+template <class KER> __global__ void __launch_bounds__(kWaveBlock) centered_mfma_stokeslet_f32_kernel(const EvalArgs<float> a) {
+  centered_mfma_stokeslet_f32_body<KER, 4>(a);
+}
+
 // The kernels.  Single layer: 256 targets per wave with one column block's MFMAs ahead = 168 registers = three waves per SIMD (asked of the compiler: left to
 // itself it issues all eight blocks' first MFMAs up front, 186 registers, two waves) — 426 against 446 ms at 2^21 for the 128-target form, which loses 3 % under
 // the same fence and gains nothing from a fourth wave (profiles/r03_ab_mfma_sl_occupancy.txt).  Double layer: 256 targets per wave, two waves per SIMD

@@ -112,7 +112,14 @@ def test_launch_planner():
                 assert sctl_amd.plan(name, 1, 1 << 20, 1 << 20)["pipe"].startswith("bf16 matrix cores")
                 assert sctl_amd.plan(name, 1, 1 << 20, 1 << 20, digits=9)["pipe"] == "vector pipe"
                 assert sctl_amd.plan(name, 0, 1 << 20, 1 << 20)["pipe"] == "vector pipe"
-        assert small["pipe"] == "vector pipe" and sctl_amd.plan("Stokes3D-FxU", 1, 1 << 20, 1 << 20)["pipe"] == "vector pipe"
+        assert small["pipe"] == "vector pipe" and sctl_amd.plan("Stokes3D-FxT", 1, 1 << 20, 1 << 20)["pipe"] == "vector pipe"
+        # ... and for the fp32 Stokeslet family (round 4: r.f is a second contraction against the same targets' operand), at the seed's accuracy only
+        if os.environ.get("SCTL_AMD_MFMA_F32") != "0":
+            for name in ("Stokes3D-FxU", "Stokes3D-FSxU", "Stokes3D-FxUP"):
+                p32 = sctl_amd.plan(name, 1, 1 << 20, 1 << 20)
+                assert p32["path"] == "tile-centred" and p32["pipe"].startswith("bf16 matrix cores") and p32["trg_per_lane"] == 2, p32
+                p9 = sctl_amd.plan(name, 1, 1 << 20, 1 << 20, digits=9)
+                assert p9["path"] == "exact" and p9["pipe"] == "vector pipe" and p9["trg_per_lane"] == 2 and p9["src_splits"] % 8 == 0, p9
         # a split's source data fits half an XCD's L2 (2 MB) and the splits come in eighths, one share per XCD (centered.hip)
         for name, real, logn in (("Laplace3D-FxU", 1, 23), ("Laplace3D-FxU", 1, 21), ("Laplace3D-DxU", 0, 20), ("Laplace3D-FxU", 0, 21)):
             p, i = sctl_amd.plan(name, real, 1 << logn, 1 << logn), sctl_amd.kernel_info(name)
@@ -196,7 +203,7 @@ def test_device_assembly_of_the_matrix_core_kernels_keeps_mfma_operands_untouche
     registers within 24 instructions of its issue (a precaution the compiler does not take by itself: DESIGN.md §4.2a)."""
     r = subprocess.run([os.sys.executable, os.path.join(ROOT, "tools", "check_mfma_operands.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert r.stdout.count("v_mfma, 0 operand write(s)") == 4, r.stdout      # the four matrix-core kernels (two shipped, two 128-target A/B forms) were found and are clean
+    assert r.stdout.count("v_mfma, 0 operand write(s)") == 7, r.stdout      # the seven matrix-core kernels (Laplace: two 256-target forms, two 128-target ones; the Stokeslet family's three) were found and are clean
 
 
 def test_device_assembly_of_every_shipped_kernel_keeps_the_isa_rules():

@@ -48,7 +48,8 @@ def test_centred_path_matches_oracle_and_exact_kernel(O, name, kind):
     f = rng.random(NS * info["k0"]) - 0.5
     xn = (rng.random(NS * 3) - 0.5) if info["nd"] else None
     assert sctl_amd.plan(name, 0, NT, NS)["path"] == "tile-centred"
-    assert sctl_amd.plan(name, 1, NT, NS)["path"] == ("tile-centred" if info["k1"] == 1 else "exact")      # vector outputs: fp64 only
+    # vector outputs in fp32: only the Stokeslet family, on the matrix cores (test_fp32_stokeslet_family_on_the_matrix_cores)
+    assert sctl_amd.plan(name, 1, NT, NS)["path"] == ("tile-centred" if info["k1"] == 1 or name.startswith("Stokes3D") else "exact")
     d = [None if a is None else torch.from_numpy(a).cuda() for a in (xt, xs, xn, f)]
     u = sctl_amd.eval_device(name, *d).cpu().numpy()
     assert np.all(np.isfinite(u))
@@ -223,6 +224,47 @@ def test_centred_fp32_contractions_on_the_matrix_cores_match_the_packed_valu_ker
     # (the double layer's signed 1/r^2 terms nearly cancel on some of these clouds: both kernels then sit further from the fp64 result, together)
     assert e_m <= (1e-4 if name.endswith("FxU") else 1e-3) and e_m <= 2 * e_v + 5e-7, (name, kind, e_m, e_v)   # measured: e_m / e_v <= 1.3 except where both are a few fp32 ulps (7.8e-7 vs 2.9e-7 on the offset cloud)
     assert rel_l2(u, u_valu) <= (2e-5 if name.endswith("FxU") else 2e-4), (name, kind, rel_l2(u, u_valu))
+
+
+@pytest.mark.parametrize("kind", ["uniform", "clustered", "surface", "identical_targets", "offset"])
+@pytest.mark.parametrize("name", ["Stokes3D-FxU", "Stokes3D-FSxU", "Stokes3D-FxUP"])
+def test_fp32_stokeslet_family_on_the_matrix_cores(O, name, kind):
+    """fp32 Stokeslet, Stokeslet + source/sink and velocity + pressure (kernel_functions.hpp:74-95, 148-198) at the default accuracy: r^2 AND (x_t - x_s).f of the far
+    pairs as split-bf16 contractions on the matrix cores, four far moments per target on the vector pipe (centered_mfma_kernel.hpp, round 4) — against the exact fp32
+    kernel and the fp64 oracle on the same fp32-rounded inputs, on the clouds that stress the far / near split, ragged sizes; accumulate semantics; more digits than the
+    seed's take the exact kernel; six evaluations bit-identical."""
+    import torch
+    rng = np.random.default_rng(654)
+    xt, xs = _clouds(kind, rng)
+    xt, xs = np.ascontiguousarray(xt.ravel()).astype(np.float32), np.ascontiguousarray(xs.ravel()).astype(np.float32)
+    info = sctl_amd.kernel_info(name)
+    f = (rng.random(NS * info["k0"]) - 0.5).astype(np.float32)
+    pl = sctl_amd.plan(name, 1, NT, NS)
+    assert pl["path"] == "tile-centred" and pl["pipe"].startswith("bf16 matrix cores") and pl["trg_per_lane"] == 2, pl
+    assert sctl_amd.plan(name, 1, NT, NS, digits=9)["path"] == "exact"                      # fp32 beyond the seed's accuracy: the exact kernel's Newton step
+    assert sctl_amd.plan(name, 0, NT, NS)["pipe"] == "vector pipe"
+    d = [torch.from_numpy(a).cuda() for a in (xt, xs, f)]
+    runs = [sctl_amd.eval_device(name, d[0], d[1], None, d[2]).clone() for _ in range(6)]
+    for r in runs[1:]:
+        assert int((r.view(torch.int32) != runs[0].view(torch.int32)).sum()) == 0, (name, kind)
+    u = runs[0].cpu().numpy()
+    assert np.all(np.isfinite(u))
+    v0 = torch.from_numpy((rng.random(NT * info["k1"]) - 0.5).astype(np.float32)).cuda()
+    u_acc = sctl_amd.eval_device(name, d[0], d[1], None, d[2], v_trg=v0.clone()).cpu().numpy()        # v_trg += (generic-kernel.txx:184)
+    assert np.max(np.abs((u_acc - v0.cpu().numpy()) - u)) <= 1e-5 * np.max(np.abs(u))
+    for env in ("SCTL_AMD_MFMA_F32", "SCTL_AMD_CENTERED"):                                              # either switch leaves the exact fp32 kernel
+        os.environ[env] = "0"
+        try:
+            assert sctl_amd.plan(name, 1, NT, NS)["path"] == "exact"
+            u_exact = sctl_amd.eval_device(name, d[0], d[1], None, d[2]).cpu().numpy()
+        finally:
+            del os.environ[env]
+    sel = rng.choice(NT, 300, replace=False)
+    ref = O.eval(name, xt.reshape(NT, 3)[sel].astype(np.float64).ravel().copy(), xs.astype(np.float64), None, f.astype(np.float64))
+    e_m, e_x = rel_l2(u.reshape(NT, -1)[sel].ravel(), ref), rel_l2(u_exact.reshape(NT, -1)[sel].ravel(), ref)
+    # the far sums run in longer fp32 chains than the exact kernel's per-tile partial sums (no registers for a second level): a few 1e-6 where the exact kernel has 5e-7
+    assert e_m <= 2e-5 and e_m <= 10 * e_x + 2e-6, (name, kind, e_m, e_x)
+    assert rel_l2(u, u_exact) <= 2e-5, (name, kind, rel_l2(u, u_exact))
 
 
 @pytest.mark.parametrize("kind", ["uniform", "clustered"])
