@@ -169,27 +169,31 @@ def test_one_process_multi_device_slabs_follow_the_morton_curve(O):
     assert rel_l2(three32[sel].astype(np.float64), ref) <= 1e-4
 
 
-def test_gradient_kernel_through_the_operator_handle_and_slabs(O):
-    """The gradient of the single layer (three outputs per target) on the tile-centred path through the entries that keep the targets in Morton order: the
-    operator handle on one device (no per-call sort: the kernel writes K1 = 3 values per target in sorted order, the handle puts them back) and three slabs of
-    one device list; accumulate and overwrite; against the host-buffer entry and the oracle."""
+@pytest.mark.parametrize("name,dt", [("Laplace3D-FxdU", np.float64), ("Stokes3D-FxUP", np.float64), ("Stokes3D-FxU", np.float32), ("Stokes3D-FxUP", np.float32)])
+def test_vector_kernels_through_the_operator_handle_and_slabs(O, name, dt):
+    """Kernels with several outputs per target on the tile-centred path (fp64: far moments on the vector pipe; fp32 Stokeslet family: the matrix-core kernel)
+    through the entries that keep the targets in Morton order: the operator handle on one device (no per-call sort: the kernel writes K1 values per target in
+    sorted order, the handle puts them back) and three slabs of one device list; accumulate and overwrite; against the host-buffer entry and the oracle."""
     rng = np.random.default_rng(43)
     n, ns = (1 << 18) + 5, 70001
-    xt, xs, f = rng.random(n * 3), rng.random(ns * 3), rng.random(ns) - 0.5
-    assert sctl_amd.plan("Laplace3D-FxdU", 0, n, ns)["path"] == "tile-centred"
-    one = sctl_amd.eval_host("Laplace3D-FxdU", xt, xs, None, f)
+    info = sctl_amd.kernel_info(name)
+    k1 = info["k1"]
+    xt, xs, f = rng.random(n * 3).astype(dt), rng.random(ns * 3).astype(dt), (rng.random(ns * info["k0"]) - 0.5).astype(dt)
+    f64 = dt == np.float64
+    assert sctl_amd.plan(name, 0 if f64 else 1, n, ns)["path"] == "tile-centred"
+    one = sctl_amd.eval_host(name, xt, xs, None, f)
     sel = rng.choice(n, 200, replace=False)
-    ref = O.eval("Laplace3D-FxdU", xt.reshape(n, 3)[sel].ravel().copy(), xs, None, f)
-    assert rel_l2(one.reshape(n, 3)[sel].ravel(), ref) <= 1e-12
+    ref = O.eval(name, xt.reshape(n, 3)[sel].astype(np.float64).ravel().copy(), xs.astype(np.float64), None, f.astype(np.float64))
+    assert rel_l2(one.reshape(n, k1)[sel].ravel(), ref) <= (1e-12 if f64 else 2e-5)
     for devs in ((0,), (0, 0, 0)):
-        op = sctl_amd.DirectOp("Laplace3D-FxdU", np.float64, devices=devs)
+        op = sctl_amd.DirectOp(name, dt, devices=devs)
         op.set_targets(xt)
         op.set_sources(xs)
-        u = np.full(n * 3, 0.25)
+        u = np.full(n * k1, 0.25, dtype=dt)
         op.eval(f, u, accumulate=True)
-        assert rel_l2(u - 0.25, one) <= 1e-13, (devs, rel_l2(u - 0.25, one))
+        assert rel_l2(u - dt(0.25), one) <= (1e-13 if f64 else 2e-5), (devs, rel_l2(u - dt(0.25), one))     # (slabs have their own cluster centres: fp32 sums differ in the last bits)
         op.eval(f, u, accumulate=False)
-        assert rel_l2(u, one) <= 2e-14
+        assert rel_l2(u, one) <= (2e-14 if f64 else 2e-5)
 
 
 @pytest.mark.parametrize("kind", ["uniform", "clustered", "surface", "identical_targets", "offset"])
