@@ -616,6 +616,54 @@ template <class KER, int CB> __device__ __forceinline__ void centered_mfma_stoke
     for (int k = 0; k < 6; k++) farS[k * kRowsCap + q] = 0;
   };
 
+  // The far moments leave the registers every kFlushTiles tiles, not only at the end: there are no registers for per-call partial sums (the second level of the other
+  // kernels' summation), and 2^20 sources in 16 splits would make fp32 chains of 16 384 terms per accumulator (rel-L2 5e-6 against fp64 where the exact kernel has 5e-7);
+  // a wave owns its targets, so it adds its finished share to the output (or its slab of partial sums) itself, in tile order: deterministic.
+  constexpr int kFlushTiles = 32;
+  bool stored = false;   // (wave-uniform) this wave has written its slab of partial sums once already
+  auto emit = [&](bool last) {
+    int le = lane;
+    asm volatile("" : "+v"(le));
+    const int me = le & 31, he = le >> 5, partner = (le ^ 32) << 2;
+    R far[kColBlocks][4];   // the two half-waves hold sums over different source rows of the same targets
+#pragma unroll
+    for (int cb = 0; cb < kColBlocks; cb++)
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const R half_sum = acc[cb][k][0] + acc[cb][k][1];
+        far[cb][k] = half_sum + __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(half_sum)));
+        acc[cb][k] = f32x2{0, 0};
+      }
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      const int64_t t = tbase + (NQ * he + q) * 32 + me;
+      const int64_t tc = (t < a.Nt) ? t : a.Nt - 1;
+      R out[K1];
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const R xtp = a.xt[tc * 3 + k] - c[k];   // x_t' (re-read: an L2 hit per flush instead of 12 registers for the whole kernel)
+        const R sk = he ? far[NQ + q][k] : far[q][k], scn = he ? far[NQ + q][3] : far[q][3];
+        out[k] = fma_(xtp, scn, sk);
+      }
+      if constexpr (K1 == 4) out[3] = he ? far[NQ + q][3] : far[q][3];
+      if (last) {
+#pragma unroll
+        for (int k = 0; k < K1; k++) out[k] += accn[q][k];
+      }
+      if (t < a.Nt) {
+#pragma unroll
+        for (int k = 0; k < K1; k++) {
+          if (gridDim.y == 1) a.v_trg[t * K1 + k] += out[k] * a.scale;
+          else {
+            R* const dst = a.partial + ((int64_t)split_idx * a.Nt + t) * K1 + k;
+            *dst = stored ? *dst + out[k] : out[k];
+          }
+        }
+      }
+    }
+    stored = true;
+  };
+
   int carry = 0;
   for (int it = 0; it < ntile; it++) {
     const int n = carry + stage_tile(it, carry), nrows = n & ~(kMfmaRows - 1);
@@ -635,6 +683,7 @@ template <class KER, int CB> __device__ __forceinline__ void centered_mfma_stoke
 #pragma unroll
       for (int k = 0; k < 6; k++) farS[k * kRowsCap + lane] = sv[k];
     }
+    if ((it & (kFlushTiles - 1)) == kFlushTiles - 1 && it + 1 < ntile) emit(false);
   }
   __syncthreads();
   if (carry > 0) {
@@ -647,38 +696,7 @@ template <class KER, int CB> __device__ __forceinline__ void centered_mfma_stoke
 
 #pragma unroll
   for (int cb = 0; cb < kColBlocks; cb++) asm volatile("" ::"v"(Bop[cb][0]), "v"(Bop[cb][1]));   // (as the Laplace kernels: every MFMA operand outlives the VALU work behind it)
-
-  int le = lane;
-  asm volatile("" : "+v"(le));
-  const int me = le & 31, he = le >> 5, partner = (le ^ 32) << 2;
-  R far[kColBlocks][4];
-#pragma unroll
-  for (int cb = 0; cb < kColBlocks; cb++)
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const R half_sum = acc[cb][k][0] + acc[cb][k][1];
-      far[cb][k] = half_sum + __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(half_sum)));
-    }
-#pragma unroll
-  for (int q = 0; q < NQ; q++) {
-    const int64_t t = tbase + (NQ * he + q) * 32 + me;
-    int64_t tc = (t < a.Nt) ? t : a.Nt - 1;
-    R out[K1];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      const R xtp = a.xt[tc * 3 + k] - c[k];   // x_t' (re-read: an L2 hit once per kernel instead of 12 registers for all of it)
-      const R sk = he ? far[NQ + q][k] : far[q][k], scn = he ? far[NQ + q][3] : far[q][3];
-      out[k] = accn[q][k] + fma_(xtp, scn, sk);
-    }
-    if constexpr (K1 == 4) out[3] = accn[q][3] + (he ? far[NQ + q][3] : far[q][3]);
-    if (t < a.Nt) {
-#pragma unroll
-      for (int k = 0; k < K1; k++) {
-        if (gridDim.y == 1) a.v_trg[t * K1 + k] += out[k] * a.scale;
-        else a.partial[((int64_t)split_idx * a.Nt + t) * K1 + k] = out[k];
-      }
-    }
-  }
+  emit(true);
 }
 template <class KER> __global__ void __launch_bounds__(kWaveBlock) centered_mfma_stokeslet_f32_kernel(const EvalArgs<float> a) {
   centered_mfma_stokeslet_f32_body<KER, 4>(a);
