@@ -266,6 +266,7 @@ int sctl_amd_comm_create(int rank, int size, const char* master_addr, int master
   }
   // The hello every rank sends: a magic word, its rank, the world size it believes in and a job token (SCTL_AMD_JOB_TOKEN, else the
   // launcher's run / job id; 0 when there is none) — rank 0 drops connections that do not belong to this job and keeps listening.
+  // The token is a guard against two jobs MIXING UP their rendezvous ports, not authentication: a job id can be guessed; keep the port off untrusted networks.
   struct Hello { uint32_t magic; int32_t rank; int32_t size; uint32_t pad; uint64_t token; };
   constexpr uint32_t kMagic = 0x5343544cu;   // "SCTL"
   uint64_t token = 0;
