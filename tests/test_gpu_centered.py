@@ -312,3 +312,54 @@ def test_centred_kernels_give_bit_identical_results_run_to_run(kind):
             finally:
                 del os.environ["SCTL_AMD_MFMA_F32"]
                 os.environ.pop("SCTL_AMD_MFMA_CB", None)
+
+
+_CENTRED_FORMS = [("Laplace3D-FxU", np.float64), ("Laplace3D-FxU", np.float32), ("Laplace3D-DxU", np.float64), ("Laplace3D-DxU", np.float32), ("Laplace3D-FxdU", np.float64),
+                  ("Stokes3D-FxUP", np.float64), ("Stokes3D-FxU", np.float32), ("Stokes3D-FSxU", np.float32), ("Stokes3D-FxUP", np.float32)]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_forced_tile_centred_paths_on_small_ragged_problems(O, seed):
+    """SCTL_AMD_CENTERED=1 sends every problem of at least 128 targets and 64 sources down the tile-centred path of its kernel (vector pipe or matrix cores): sizes around
+    the 64-source tile, the 32-row contraction block and the 128 / 192 / 256 targets of a wave, a single partly filled wave, coincident points (targets copied from
+    sources), scaled clouds, every accuracy the form serves, through device tensors, host buffers and the operator handle — each against the CPU oracle on the same inputs."""
+    import torch
+    rng = np.random.default_rng(4200 + seed)
+    os.environ["SCTL_AMD_CENTERED"] = "1"
+    try:
+        for _ in range(14):
+            name, dt = _CENTRED_FORMS[int(rng.integers(0, len(_CENTRED_FORMS)))]
+            info = sctl_amd.kernel_info(name)
+            f64 = dt == np.float64
+            Nt = int(rng.choice([128, 129, 191, 192, 193, 255, 256, 257, 383, 385, 513])) if rng.random() < 0.5 else int(rng.integers(128, 3000))
+            Ns = int(rng.choice([64, 65, 95, 96, 97, 127, 128, 129, 191, 193])) if rng.random() < 0.5 else int(rng.integers(64, 3000))
+            digits = int(rng.choice([-1, -1, 12, 9, 5])) if f64 else int(rng.choice([-1, -1, 5]))
+            scale = float(rng.choice([1.0, 1e-3, 1e3]))
+            xs = (scale * rng.random(Ns * 3)).astype(dt)
+            xt = (scale * (rng.random(Nt * 3) if rng.random() < 0.7 else 0.2 * rng.random(Nt * 3) + 0.4)).astype(dt)
+            if rng.random() < 0.4:                  # coincident points: every such pair contributes exactly 0 (kernel_functions.hpp:28)
+                k = min(Nt, Ns, int(rng.integers(1, 200)))
+                xt[:k * 3] = xs[:k * 3]
+            xn = (rng.random(Ns * info["nd"]) - 0.5).astype(dt)
+            f = (rng.random(Ns * info["k0"]) - 0.5).astype(dt)
+            pl = sctl_amd.plan(name, 0 if f64 else 1, Nt, Ns, digits=digits)
+            assert pl["path"] == "tile-centred", (name, dt.__name__, Nt, Ns, digits, pl)
+            ref = O.eval(name, xt.astype(np.float64), xs.astype(np.float64), xn.astype(np.float64), f.astype(np.float64))
+            how = int(rng.integers(0, 3))
+            if how == 0:
+                u = sctl_amd.eval_host(name, xt, xs, xn, f, digits=digits)
+            elif how == 1:
+                d = [torch.from_numpy(a).cuda() for a in (xt, xs, xn, f)]
+                u = sctl_amd.eval_device(name, *d, digits=digits).cpu().numpy()
+            else:
+                op = sctl_amd.DirectOp(name, dt)
+                op.set_targets(xt)
+                op.set_sources(xs, xn)
+                u = op.eval(f, digits=digits)
+                op.close()
+            tol = (1e-12 if digits < 0 else 10.0 * 10.0 ** (-digits)) if f64 else (3e-5 if digits != 5 else 1e-4)
+            err = rel_l2(u, ref)
+            assert np.all(np.isfinite(u)) and err <= tol, (name, dt.__name__, Nt, Ns, digits, how, scale, err)
+    finally:
+        del os.environ["SCTL_AMD_CENTERED"]
+
