@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: pair-interactions/s of the Laplace single-layer N x N direct sum on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload laplace_sl|laplace_sldl|stokeslet|helmholtz|laplace_sl_f32]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload laplace_sl|laplace_sldl|stokeslet|helmholtz|laplace_sl_f32|stokeslet_f32|laplace_sl_16k|p2p_lists|near_apply]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" is one full evaluation of the hot path over one synthetic point cloud that is already resident in HBM:
@@ -30,6 +30,7 @@ WORKLOADS = {
     "stokeslet": ("Stokes3D-FxU", 1 << 18, "f64", "Stokes3D Stokeslet (Stokes3D-FxU), 2^18 x 2^18, fp64 [BASELINE configs[2]]"),
     "laplace_sl_f32": ("Laplace3D-FxU", 1 << 23, "f32", "Laplace3D single layer, 2^23 x 2^23, fp32 [BASELINE configs[3]; needs >= 8 GPUs to finish in minutes]"),
     "helmholtz": ("Helmholtz3D-FxU", 1 << 20, "f64", "Helmholtz3D single layer k = 7.5 + 0.3i (Helmholtz3D-FxU), 2^20 x 2^20, fp64 [BASELINE configs[4]]"),
+    "stokeslet_f32": ("Stokes3D-FxU", 1 << 20, "f32", "Stokes3D Stokeslet (Stokes3D-FxU), 2^20 x 2^20, fp32 [not a BASELINE config: the reference runs every functor at Real = float, generic-kernel.txx:76]"),
     "laplace_sl_16k": ("Laplace3D-FxU", 1 << 14, "f64", "Laplace3D single layer, 2^14 x 2^14, fp64 [BASELINE configs[0], the reference's CPU-runnable case]"),
 }
 PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}   # vector FMA peaks, BASELINE.md §3 / MI355X_MICROARCH.md chip table
@@ -456,7 +457,7 @@ def main():
             # has the same dense peak as the fp64 (fp32) MFMA path, 78.6 (157.3) TFLOP/s, and shares its issue slots
             # (fp32 Laplace SL takes the far pairs' r^2 from the bf16 matrix cores, sctl_amd_eval_pipe; the fraction stays against the fp32 peak)
             "roofline": {"bound": "mfma", "pipe": ("fp64 VALU" if dtype == "f64" else "fp32 VALU") if plan["pipe"] == "vector pipe" else
-                                                  "bf16 MFMA (r^2 as a split-bf16 contraction, K = 30) + fp32 VALU (v_rsq_f32, accumulate)",
+                                                  "bf16 MFMA (r^2%s as split-bf16 contractions, K = 30) + fp32 VALU (v_rsq_f32, accumulate)" % ("" if kernel == "Laplace3D-FxU" else " and the dot product"),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": read_traffic(args.workload) if world == 1 else None,
                          "flops_per_pair": fpp, "kernel_ms": k_ms,

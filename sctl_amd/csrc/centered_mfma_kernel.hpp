@@ -617,9 +617,10 @@ template <class KER, int CB> __device__ __forceinline__ void centered_mfma_stoke
   };
 
   // The far moments leave the registers every kFlushTiles tiles, not only at the end: there are no registers for per-call partial sums (the second level of the other
-  // kernels' summation), and 2^20 sources in 16 splits would make fp32 chains of 16 384 terms per accumulator (rel-L2 5e-6 against fp64 where the exact kernel has 5e-7);
-  // a wave owns its targets, so it adds its finished share to the output (or its slab of partial sums) itself, in tile order: deterministic.
-  constexpr int kFlushTiles = 32;
+  // kernels' summation), so this bounds the fp32 chains — 16 384 sources = 4 096 terms per accumulator — whatever the source count.  A wave owns its targets: it adds its
+  // finished share to the output (or its slab of partial sums) itself, in tile order: deterministic.  (Every 32 tiles instead: rel-L2 against fp64 3.8e-6 for 4.0e-6 at
+  // 2^20 and 3 GB more partial-sum traffic per launch — the error is the contraction's, not the chains'.)
+  constexpr int kFlushTiles = 256;
   bool stored = false;   // (wave-uniform) this wave has written its slab of partial sums once already
   auto emit = [&](bool last) {
     int le = lane;
