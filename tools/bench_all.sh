@@ -2,7 +2,7 @@ set -u
 mkdir -p gpurun_out/${TAG:-r04}_bench
 python bench.py > gpurun_out/${TAG:-r04}_bench/n1.json 2> gpurun_out/${TAG:-r04}_bench/n1.err
 python bench.py --steps 20 --warmup 3 > gpurun_out/${TAG:-r04}_bench/n1_driver_style.json 2>> gpurun_out/${TAG:-r04}_bench/n1.err
-for w in laplace_sl_16k laplace_sldl stokeslet helmholtz p2p_lists near_apply; do
+for w in laplace_sl_16k laplace_sldl stokeslet stokeslet_f32 helmholtz p2p_lists near_apply; do
   st=5; [ $w = laplace_sl_16k ] && st=200
   python bench.py --workload $w --steps $st --warmup 2 > gpurun_out/${TAG:-r04}_bench/$w.json 2>> gpurun_out/${TAG:-r04}_bench/n1.err
 done

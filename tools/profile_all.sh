@@ -4,7 +4,7 @@
 #   tools/profile_all.sh <tag> [workload ...]
 set -u
 tag=${1:-r02}; shift || true
-wl=${*:-laplace_sl laplace_sl_16k laplace_sldl stokeslet helmholtz p2p_lists near_apply}
+wl=${*:-laplace_sl laplace_sl_16k laplace_sldl stokeslet stokeslet_f32 helmholtz p2p_lists near_apply}
 for w in $wl; do
   echo "== $w"
   tools/profile_bench.sh ${tag}_$w --workload $w || { echo "profiling $w failed"; exit 1; }
