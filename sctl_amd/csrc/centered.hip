@@ -36,7 +36,7 @@ bool use_mfma_f32() {
 // (what sctl_amd_eval_pipe reports; must say what launch_centered does)
 int centered_pipe(int kernel_id, int real, int mode) {
   const bool has = kernel_id == Laplace3D_FxU::ID || kernel_id == Laplace3D_DxU::ID || kernel_id == Stokes3D_FxU::ID || kernel_id == Stokes3D_FSxU::ID ||
-                   kernel_id == Stokes3D_FxUP::ID;   // (the Stokeslet family, round 4: r.f is a second contraction, as the double layer's numerator)
+                   kernel_id == Stokes3D_FxUP::ID || kernel_id == Stokes3D_DxU::ID || kernel_id == Stokes3D_FxT::ID;   // (Stokeslet family and stresslet, round 4: r.f, r.n are further contractions, as the double layer's numerator)
   return (has && real == 1 /* SCTL_AMD_F32 */ && mode == 0 && use_mfma_f32()) ? 2 : 1;
 }
 // Targets per wave (= per workgroup) of that path: 64 per target of a lane on the vector pipe (the policy's targets_per_lane); for the matrix-core kernels 256 = eight
@@ -55,16 +55,21 @@ int centered_targets_per_wave(int kernel_id, int real, int mode, int64_t density
     if (e[0] == '8') return 256;
     if (e[0] == '4') return 128;
   }
-  if (kernel_id != Laplace3D_FxU::ID && kernel_id != Laplace3D_DxU::ID) return 128;   // the Stokeslet family: four column blocks
+  if (kernel_id != Laplace3D_FxU::ID && kernel_id != Laplace3D_DxU::ID) return 128;   // the Stokeslet family, the stresslet: four column blocks
   return (kernel_id == Laplace3D_FxU::ID && density < ((int64_t)1 << 20)) ? 128 : 256;
 }
 namespace {
-template <class CP> struct stokeslet_policy_kernel { using type = void; };
-template <class R, class KER> struct stokeslet_policy_kernel<CenteredStokeslet<R, KER>> { using type = KER; };
+// fp32 kernels with several outputs per target: the policy of centered_mfma_moments_f32_kernel that serves a tile-centred policy (void: none)
+template <class R> struct CenteredStresslet { using Ker = Stokes3D_DxU; };   // (fp32 only: a tag for eval_centered_t; the stresslet has no vector-pipe centred form)
+template <class CP> struct mfma_moments_policy { using type = void; };
+template <class KER> struct mfma_moments_policy<CenteredStokeslet<float, KER>> { using type = MfmaStokeslet<KER>; };
+template <> struct mfma_moments_policy<CenteredStresslet<float>> { using type = MfmaStresslet; };
+template <class R> struct CenteredTraction { using Ker = Stokes3D_FxT; };
+template <> struct mfma_moments_policy<CenteredTraction<float>> { using type = MfmaTraction; };
 template <class CP, class R, int MODE> void launch_centered(const EvalArgs<R>& a, dim3 grid, int per_wave, hipStream_t st) {
-  using SK = typename stokeslet_policy_kernel<CP>::type;
-  if constexpr (std::is_same<R, float>::value && !std::is_void<SK>::value) {   // fp32 Stokeslet family: the matrix-core kernel at the seed's accuracy, nothing else
-    if constexpr (MODE == 0) hipLaunchKernelGGL((centered_mfma_stokeslet_f32_kernel<SK>), grid, dim3(kWaveBlock), 0, st, a);   // (capi.hip asks for this path at MODE 0 only)
+  using MP = typename mfma_moments_policy<CP>::type;
+  if constexpr (std::is_same<R, float>::value && !std::is_void<MP>::value) {   // the matrix-core moments kernel at the seed's accuracy, nothing else
+    if constexpr (MODE == 0) hipLaunchKernelGGL((centered_mfma_moments_f32_kernel<MP>), grid, dim3(kWaveBlock), 0, st, a);   // (capi.hip asks for this path at MODE 0 only)
     return;
   } else {
   if constexpr (std::is_same<R, float>::value && MODE == 0) {
@@ -222,6 +227,8 @@ hipError_t eval_centered(int kernel_id, int64_t Nt, int64_t Ns, const R* xt, con
     if (kernel_id == Stokes3D_FxU::ID) return eval_centered_t<CenteredStokeslet<R, Stokes3D_FxU>, R>(Nt, Ns, xt, xs, xn, f, v_trg, scale, mode, cus, st, presorted, density);
     if (kernel_id == Stokes3D_FSxU::ID) return eval_centered_t<CenteredStokeslet<R, Stokes3D_FSxU>, R>(Nt, Ns, xt, xs, xn, f, v_trg, scale, mode, cus, st, presorted, density);
     if (kernel_id == Stokes3D_FxUP::ID) return eval_centered_t<CenteredStokeslet<R, Stokes3D_FxUP>, R>(Nt, Ns, xt, xs, xn, f, v_trg, scale, mode, cus, st, presorted, density);
+    if (kernel_id == Stokes3D_DxU::ID) return eval_centered_t<CenteredStresslet<R>, R>(Nt, Ns, xt, xs, xn, f, v_trg, scale, mode, cus, st, presorted, density);
+    if (kernel_id == Stokes3D_FxT::ID) return eval_centered_t<CenteredTraction<R>, R>(Nt, Ns, xt, xs, xn, f, v_trg, scale, mode, cus, st, presorted, density);
   }
   return eval_centered_t<CenteredFxU<R>, R>(Nt, Ns, xt, xs, xn, f, v_trg, scale, mode, cus, st, presorted, density);
 }

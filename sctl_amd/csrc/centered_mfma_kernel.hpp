@@ -383,25 +383,132 @@ template <bool DL, int CB, bool STEP> __device__ __forceinline__ void centered_m
   }
 }
 
-// ---- the Stokeslet family in fp32 (Stokes3D_FxU / _FSxU / _FxUP, kernel_functions.hpp:74-95, 148-198; round 4) --------------------------------------------------
-// u_j = sum_s (f_j + r_j (r.f) / r^2) / r.  r.f is a second contraction against the SAME B operand, exactly as the double layer's numerator (rows of -f/2 against
-// -2 x_t', -x_s'.f against the ones; Stokes3D_FSxU adds its source strength to that constant), so the matrix cores hand the vector pipe r2 and r.f of 32 x 32 pairs
-// and the pipe is left with v_rsq_f32, t = (r.f) y^2, c = t y and the FOUR moments of CenteredStokeslet (centered_kernel.hpp): S_c += c, S_j += y f_j - c x_s'_j,
-// u_j = S_j + x_t'_j S_c — seven packed instructions per two pairs.  f_j and x_s'_j belong to the lane's 16 source rows: kept in LDS component by component, four
-// consecutive rows per 16-byte read, re-read for every column block in two halves (all sixteen rows of six components at once would take 96 registers).
-// 128 targets per wave (four column blocks), two waves per SIMD.  Stokes3D_FxUP's pressure is S_c.  fp32, MODE 0 only.
-template <class KER, int CB> __device__ __forceinline__ void centered_mfma_stokeslet_f32_body(const EvalArgs<float>& a) {
-  using R = float;
+// ---- kernels with several outputs per target in fp32: far MOMENTS on the vector pipe, every dot product of the pair on the matrix cores (round 4) -----------------------
+// The Stokeslet family (Stokes3D_FxU / _FSxU / _FxUP, kernel_functions.hpp:74-95, 148-198): u_j = sum_s (f_j + r_j (r.f) / r^2) / r.  r.f is a second contraction
+// against the SAME B operand, exactly as the double layer's numerator (rows of -f/2 against -2 x_t', -x_s'.f against the ones; Stokes3D_FSxU adds its source strength
+// to that constant), so the matrix cores hand the vector pipe r2 and r.f of 32 x 32 pairs and the pipe is left with v_rsq_f32, t = (r.f) y^2, c = t y and the FOUR
+// moments of CenteredStokeslet (centered_kernel.hpp): S_c += c, S_j += y f_j - c x_s'_j, u_j = S_j + x_t'_j S_c — ten packed instructions per two pairs.  Stokes3D_FxUP's
+// pressure is S_c.  The stresslet (Stokes3D_DxU, kernel_functions.hpp:97-120): u_j = sum_s r_j (r.f)(r.n) / r^5 takes TWO numerator contractions and the moments
+// S_c = sum c, S_j = sum c x_s'_j with c = (r.f)(r.n) y^5, u_j = x_t'_j S_c - S_j.
+// The per-source values the moments need (f_j, x_s'_j) belong to the lane's 16 source rows: kept in LDS component by component, four consecutive rows per 16-byte
+// read, read ONCE per 32-row block for all column blocks (re-reading them per column block made the loop LDS-bound: profiles/r04_ab_stokes_f32.txt).
+// 128 targets per wave (four column blocks), two waves per SIMD.  fp32, MODE 0 only.
+//
+// A policy MP says: Ker; NNUM numerator contractions; NSC per-source scalars; PREBUILT — whether the staging lane writes the numerators' bf16 rows (four 16-byte words
+// each) or only their four fp32 coefficients, the rows then being cut into pieces by the lanes that feed them to the matrix cores (a quarter of the LDS; ~25 vector
+// instructions per numerator and 32-row block); numerators(), scalars(), pairs() (two source rows of one target at a time), finish().
+template <class KER> struct MfmaStokeslet {
   using Ker = KER;
-  static_assert((Ker::K0 == 3 || Ker::K0 == 4) && (Ker::K1 == 3 || Ker::K1 == 4) && Ker::ND == 0, "the Stokeslet family");
-  constexpr int kColBlocks = CB, NQ = CB / 2, K0 = Ker::K0, K1 = Ker::K1;
+  static_assert((KER::K0 == 3 || KER::K0 == 4) && (KER::K1 == 3 || KER::K1 == 4) && KER::ND == 0, "the Stokeslet family");
+  static constexpr int NNUM = 1, NSC = 6, NM = 4;
+  static constexpr bool PREBUILT = true, AHEAD = false;   // (252 registers: none left to keep a column block's contractions ahead)
+  static __device__ __forceinline__ void numerators(float (&num)[NNUM][4], const float (&p)[3], const float*, const float* f) {
+    float g3 = -(p[0] * f[0] + p[1] * f[1] + p[2] * f[2]);
+    if constexpr (KER::K0 == 4) g3 += f[3];
+    num[0][0] = -0.5f * f[0]; num[0][1] = -0.5f * f[1]; num[0][2] = -0.5f * f[2]; num[0][3] = g3;
+  }
+  static __device__ __forceinline__ void scalars(float (&sc)[NSC], const float (&p)[3], const float*, const float* f) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) { sc[k] = f[k]; sc[3 + k] = p[k]; }
+  }
+  static __device__ __forceinline__ void pairs(f32x2 (&acc)[NM], f32x2 y, const f32x2 (&dn)[NNUM], const f32x2 (&s)[NSC]) {
+    const f32x2 t = dn[0] * (y * y);
+    const f32x2 cc = t * y;
+    acc[3] += cc;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      acc[j] += y * s[j];
+      acc[j] -= cc * s[3 + j];
+    }
+  }
+  static __device__ __forceinline__ void finish(float (&out)[KER::K1], const float (&far)[NM], const float (&xtp)[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) out[k] = fma_(xtp[k], far[3], far[k]);
+    if constexpr (KER::K1 == 4) out[3] = far[3];
+  }
+};
+struct MfmaStresslet {
+  using Ker = Stokes3D_DxU;
+  static constexpr int NNUM = 2, NSC = 3, NM = 4;
+  static constexpr bool PREBUILT = false, AHEAD = true;   // (three prebuilt rows per source would be 20 KB of LDS per wave: three waves per TWO SIMDs)
+  static __device__ __forceinline__ void numerators(float (&num)[NNUM][4], const float (&p)[3], const float* n, const float* f) {
+    num[0][0] = -0.5f * f[0]; num[0][1] = -0.5f * f[1]; num[0][2] = -0.5f * f[2]; num[0][3] = -(p[0] * f[0] + p[1] * f[1] + p[2] * f[2]);
+    num[1][0] = -0.5f * n[0]; num[1][1] = -0.5f * n[1]; num[1][2] = -0.5f * n[2]; num[1][3] = -(p[0] * n[0] + p[1] * n[1] + p[2] * n[2]);
+  }
+  static __device__ __forceinline__ void scalars(float (&sc)[NSC], const float (&p)[3], const float*, const float*) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) sc[k] = p[k];
+  }
+  static __device__ __forceinline__ void pairs(f32x2 (&acc)[NM], f32x2 y, const f32x2 (&dn)[NNUM], const f32x2 (&s)[NSC]) {
+    const f32x2 y2 = y * y, y4 = y2 * y2;
+    const f32x2 cc = (dn[0] * dn[1]) * (y4 * y);
+    acc[3] += cc;
+#pragma unroll
+    for (int j = 0; j < 3; j++) acc[j] -= cc * s[j];
+  }
+  static __device__ __forceinline__ void finish(float (&out)[3], const float (&far)[NM], const float (&xtp)[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) out[k] = fma_(xtp[k], far[3], far[k]);
+  }
+};
+// the traction tensor (Stokes3D_FxT, kernel_functions.hpp:122-146): u_jk = sum_s (r.f) r_j r_k / r^5.  With c = (r.f) y^5 and r = x_t' - x_s':
+// u_jk = x_t'_j x_t'_k S_c - x_t'_j S_k - S_j x_t'_k + S_jk, S_c = sum c, S_j = sum c x_s'_j, S_jk = sum c x_s'_j x_s'_k (six of them): ten moments, the products
+// c x_s'_j made once per pair and used for S_j and S_jk — 17 packed instructions per two pairs where the exact pair has 2 x 21.
+struct MfmaTraction {
+  using Ker = Stokes3D_FxT;
+  static constexpr int NNUM = 1, NSC = 3, NM = 10;
+  static constexpr bool PREBUILT = false, AHEAD = false;
+  static __device__ __forceinline__ void numerators(float (&num)[NNUM][4], const float (&p)[3], const float*, const float* f) {
+    num[0][0] = -0.5f * f[0]; num[0][1] = -0.5f * f[1]; num[0][2] = -0.5f * f[2]; num[0][3] = -(p[0] * f[0] + p[1] * f[1] + p[2] * f[2]);
+  }
+  static __device__ __forceinline__ void scalars(float (&sc)[NSC], const float (&p)[3], const float*, const float*) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) sc[k] = p[k];
+  }
+  static __device__ __forceinline__ void pairs(f32x2 (&acc)[NM], f32x2 y, const f32x2 (&dn)[NNUM], const f32x2 (&s)[NSC]) {
+    const f32x2 y2 = y * y, y4 = y2 * y2;
+    const f32x2 cc = dn[0] * (y4 * y);
+    acc[0] += cc;
+    int q = 4;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const f32x2 cx = cc * s[j];
+      acc[1 + j] += cx;
+#pragma unroll
+      for (int k = j; k < 3; k++) acc[q++] += cx * s[k];     // S_xx, S_xy, S_xz, S_yy, S_yz, S_zz
+    }
+  }
+  static __device__ __forceinline__ void finish(float (&out)[9], const float (&far)[NM], const float (&xtp)[3]) {
+    int q = 4;
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+      for (int k = j; k < 3; k++) {
+        const float v = fma_(xtp[j] * xtp[k], far[0], far[q++]) - xtp[j] * far[1 + k] - far[1 + j] * xtp[k];
+        out[j * 3 + k] = v;
+        out[k * 3 + j] = v;
+      }
+  }
+};
+// the two contraction words of lane (row, h) for a numerator kept as {c_x, c_y, c_z, constant}: K entries 8 h .. 8 h + 7 of step 0 and of step 1
+__device__ __forceinline__ void numerator_words(f32x4 v, int h, u32x4& s0, u32x4& s1) {
+  s0 = a_word(h ? v[1] : v[0]);
+  const u32x4 wz = a_word(v[2]), wt = a_tail(v[3], false);
+#pragma unroll
+  for (int i = 0; i < 4; i++) s1[i] = h ? wt[i] : wz[i];
+}
+
+template <class MP, int CB> __device__ __forceinline__ void centered_mfma_moments_f32_body(const EvalArgs<float>& a) {
+  using R = float;
+  using Ker = typename MP::Ker;
+  constexpr int kColBlocks = CB, NQ = CB / 2, K0 = Ker::K0, K1 = Ker::K1, ND = Ker::ND, NNUM = MP::NNUM, NSC = MP::NSC, NM = MP::NM;
   using V = Rec4<R>::V;
   constexpr int NEARW = (Ker::NREC + 3) / 4;
-  constexpr int RW = 9;                         // r2 row, r.f row, one word of padding
+  constexpr int RW = MP::PREBUILT ? 4 * (1 + NNUM) + 1 : 4 + NNUM + 1;   // the r2 row, the numerators (rows, or four coefficients each), one word of padding
   constexpr int kRowsCap = kWaveTile + kMfmaRows, kRows4 = kRowsCap / 4;
   constexpr int kNear = 64;                     // pending near sources (three words each; with 128 the workgroup's LDS would leave one wave per SIMD)
   __shared__ u32x4 farA[kRowsCap * RW];
-  __shared__ f32x4 farS4[6 * kRows4];           // f_0, f_1, f_2, x', y', z' of the far rows, one array per component
+  __shared__ f32x4 farS4[NSC * kRows4];         // the per-source scalars of the far rows, one array per component
   __shared__ V nearA[(kNear + 2) * NEARW];
   float* const farS = (float*)farS4;
 
@@ -450,11 +557,11 @@ template <class KER, int CB> __device__ __forceinline__ void centered_mfma_stoke
   rt2 = uniform_(wave_max(rt2));
   const R near_r2 = R(a.ctx.v[0]) * rt2;
 
-  f32x2 acc[kColBlocks][4];   // the four far moments of this half-wave's source rows, per column block: {even rows, odd rows}
+  f32x2 acc[kColBlocks][NM];   // the far moments of this half-wave's source rows, per column block: {even rows, odd rows}
 #pragma unroll
   for (int cb = 0; cb < kColBlocks; cb++)
 #pragma unroll
-    for (int k = 0; k < 4; k++) acc[cb][k] = f32x2{0, 0};
+    for (int k = 0; k < NM; k++) acc[cb][k] = f32x2{0, 0};
   R accn[NQ][K1];
 #pragma unroll
   for (int q = 0; q < NQ; q++)
@@ -466,7 +573,7 @@ template <class KER, int CB> __device__ __forceinline__ void centered_mfma_stoke
   const int64_t len = (s_end > s_begin) ? s_end - s_begin : 0;
   const int ntile = (int)((len + kWaveTile - 1) / kWaveTile);
 
-  R x[3] = {0, 0, 0}, f[K0];
+  R x[3] = {0, 0, 0}, nrm[3] = {0, 0, 0}, f[K0];
 #pragma unroll
   for (int k = 0; k < K0; k++) f[k] = 0;
   auto load_source = [&](int it) {
@@ -475,15 +582,16 @@ template <class KER, int CB> __device__ __forceinline__ void centered_mfma_stoke
 #pragma unroll
       for (int k = 0; k < 3; k++) x[k] = a.xs[s * 3 + k];
 #pragma unroll
+      for (int k = 0; k < ND; k++) nrm[k] = a.xn[s * ND + k];
+#pragma unroll
       for (int k = 0; k < K0; k++) f[k] = a.f[s * K0 + k];
     }
   };
   if (ntile > 0) load_source(0);
 
   const R far_off = uniform_(R(1.0e3) * (R(1) + sqrt_(rt2)));
-  auto put_near = [&](int q, const R (&xq)[3], const R (&fq)[K0]) {
+  auto put_near = [&](int q, const R (&xq)[3], const R (&nq)[3], const R (&fq)[K0]) {
     R rec[4 * NEARW] = {};
-    const R nq[3] = {0, 0, 0};
     pack_record<Ker, R, 0>(rec, xq, nq, fq);
 #pragma unroll
     for (int g = 0; g < NEARW; g++) Rec4<R>::put(nearA + q * NEARW + g, rec[4 * g], rec[4 * g + 1], rec[4 * g + 2], rec[4 * g + 3]);
@@ -494,8 +602,8 @@ template <class KER, int CB> __device__ __forceinline__ void centered_mfma_stoke
       if (lane == 0) {
         R cx = c[0], fo = far_off;
         asm volatile("" : "+v"(cx), "+v"(fo));
-        const R xq[3] = {cx + fo, c[1], c[2]}, fq[K0] = {};
-        put_near(nn, xq, fq);
+        const R xq[3] = {cx + fo, c[1], c[2]}, nq[3] = {0, 0, 0}, fq[K0] = {};
+        put_near(nn, xq, nq, fq);
       }
       __syncthreads();
     }
@@ -553,16 +661,24 @@ template <class KER, int CB> __device__ __forceinline__ void centered_mfma_stoke
       row[1] = a_word(p[1]);
       row[2] = a_word(p[2]);
       row[3] = a_tail(ss, true);
-      row[4] = a_word(R(-0.5) * f[0]);
-      row[5] = a_word(R(-0.5) * f[1]);
-      row[6] = a_word(R(-0.5) * f[2]);
-      R g3 = -(p[0] * f[0] + p[1] * f[1] + p[2] * f[2]);
-      if constexpr (K0 == 4) g3 += f[3];
-      row[7] = a_tail(g3, false);
+      R num[NNUM][4], sc[NSC];
+      MP::numerators(num, p, nrm, f);
+      MP::scalars(sc, p, nrm, f);
 #pragma unroll
-      for (int k = 0; k < 3; k++) { farS[k * kRowsCap + q] = f[k]; farS[(3 + k) * kRowsCap + q] = p[k]; }
+      for (int n = 0; n < NNUM; n++) {
+        if constexpr (MP::PREBUILT) {
+          row[4 + 4 * n] = a_word(num[n][0]);
+          row[5 + 4 * n] = a_word(num[n][1]);
+          row[6 + 4 * n] = a_word(num[n][2]);
+          row[7 + 4 * n] = a_tail(num[n][3], false);
+        } else {
+          row[4 + n] = __builtin_bit_cast(u32x4, f32x4{num[n][0], num[n][1], num[n][2], num[n][3]});
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NSC; k++) farS[k * kRowsCap + q] = sc[k];
     } else if (is_near) {
-      put_near(nn + __popcll(bn & below), x, f);
+      put_near(nn + __popcll(bn & below), x, nrm, f);
     }
     nn += nnear;
     return nfar;
@@ -572,48 +688,66 @@ template <class KER, int CB> __device__ __forceinline__ void centered_mfma_stoke
     const f32x16 zero = {};
     int lr = lane;
     asm volatile("" : "+v"(lr));
-    const u32x4* const row0 = farA + (lr & 31) * RW + (lr >> 5);
+    const u32x4* const row0 = farA + (lr & 31) * RW + (MP::PREBUILT ? (lr >> 5) : 0);
     const f32x4* const sc0 = farS4 + (lr >> 5);
     for (int r0 = 0; r0 < nrows; r0 += kMfmaRows) {
       const u32x4* row = row0 + r0 * RW;
-      const u32x4 A0 = row[0], A1 = row[2], G0 = row[4], G1 = row[6];
-      const f32x4* const sc = sc0 + (r0 >> 2);
-      f32x4 w[6][4];   // f_j and x_s'_j of this lane's sixteen rows 8 k + 4 h + {0..3}: read once per row block, used by every column block
+      u32x4 A0, A1, G0[NNUM], G1[NNUM];
+      if constexpr (MP::PREBUILT) {
+        A0 = row[0]; A1 = row[2];
 #pragma unroll
-      for (int comp = 0; comp < 6; comp++)
+        for (int n = 0; n < NNUM; n++) { G0[n] = row[4 + 4 * n]; G1[n] = row[6 + 4 * n]; }
+      } else {
+        A0 = row[lr >> 5]; A1 = row[2 + (lr >> 5)];
+#pragma unroll
+        for (int n = 0; n < NNUM; n++) numerator_words(__builtin_bit_cast(f32x4, row[4 + n]), lr >> 5, G0[n], G1[n]);
+      }
+      const f32x4* const sc = sc0 + (r0 >> 2);
+      f32x4 w[NSC][4];   // the scalars of this lane's sixteen rows 8 k + 4 h + {0..3}: read once per row block, used by every column block
+#pragma unroll
+      for (int comp = 0; comp < NSC; comp++)
 #pragma unroll
         for (int k = 0; k < 4; k++) w[comp][k] = sc[comp * kRows4 + 2 * k];
+      f32x16 r2 = mfma(A1, Bop[0][1], mfma(A0, Bop[0][0], zero));
 #pragma unroll
       for (int cb = 0; cb < kColBlocks; cb++) {
-        f32x16 r2 = mfma(A1, Bop[cb][1], mfma(A0, Bop[cb][0], zero)), rn = mfma(G1, Bop[cb][1], mfma(G0, Bop[cb][0], zero));
+        f32x16 rn[NNUM];
+#pragma unroll
+        for (int n = 0; n < NNUM; n++) rn[n] = mfma(G1[n], Bop[cb][1], mfma(G0[n], Bop[cb][0], zero));
+        f32x16 r2n = r2;
+        if constexpr (MP::AHEAD) {   // the next block's distances on the matrix cores while the vector pipe works on this one's
+          if (cb + 1 < kColBlocks) r2n = mfma(A1, Bop[cb + 1][1], mfma(A0, Bop[cb + 1][0], zero));
+        }
 #pragma unroll
         for (int v = 0; v < 16; v++) r2[v] = __builtin_amdgcn_rsqf(r2[v]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int v = 0; v < 16; v += 2) {
           const int k = v >> 2, e = v & 3;
-          const f32x2 y = {r2[v], r2[v + 1]};
-          const f32x2 t = f32x2{rn[v], rn[v + 1]} * (y * y);
-          const f32x2 cc = t * y;
-          acc[cb][3] += cc;
+          f32x2 dn[NNUM], s[NSC];
 #pragma unroll
-          for (int j = 0; j < 3; j++) {
-            acc[cb][j] += y * f32x2{w[j][k][e], w[j][k][e + 1]};
-            acc[cb][j] -= cc * f32x2{w[3 + j][k][e], w[3 + j][k][e + 1]};
-          }
+          for (int n = 0; n < NNUM; n++) dn[n] = f32x2{rn[n][v], rn[n][v + 1]};
+#pragma unroll
+          for (int j = 0; j < NSC; j++) s[j] = f32x2{w[j][k][e], w[j][k][e + 1]};
+          MP::pairs(acc[cb], f32x2{r2[v], r2[v + 1]}, dn, s);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MP::AHEAD) r2 = r2n;
+        else if (cb + 1 < kColBlocks) r2 = mfma(A1, Bop[cb + 1][1], mfma(A0, Bop[cb + 1][0], zero));
       }
-      asm volatile("" ::"v"(A0), "v"(A1), "v"(G0), "v"(G1));   // operands stay untouched until the VALU work behind the last MFMA is done
+      asm volatile("" ::"v"(A0), "v"(A1));   // operands stay untouched until the VALU work behind the last MFMA is done
+#pragma unroll
+      for (int n = 0; n < NNUM; n++) asm volatile("" ::"v"(G0[n]), "v"(G1[n]));
     }
   };
-  auto put_null_far = [&](int q) {   // r2 = 1 + |x_t'|^2 > 0, zero numerator, zero density: contributes exactly 0
+  auto put_null_far = [&](int q) {   // r2 = 1 + |x_t'|^2 > 0, zero numerators, zero scalars: contributes exactly 0
     u32x4* row = farA + q * RW;
     row[0] = row[1] = row[2] = u32x4{0, 0, 0, 0};
     row[3] = a_tail(1.0f, true);
-    row[4] = row[5] = row[6] = row[7] = u32x4{0, 0, 0, 0};
 #pragma unroll
-    for (int k = 0; k < 6; k++) farS[k * kRowsCap + q] = 0;
+    for (int i = 4; i < RW - 1; i++) row[i] = u32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < NSC; k++) farS[k * kRowsCap + q] = 0;
   };
 
   // The far moments leave the registers every kFlushTiles tiles, not only at the end: there are no registers for per-call partial sums (the second level of the other
@@ -626,11 +760,11 @@ template <class KER, int CB> __device__ __forceinline__ void centered_mfma_stoke
     int le = lane;
     asm volatile("" : "+v"(le));
     const int me = le & 31, he = le >> 5, partner = (le ^ 32) << 2;
-    R far[kColBlocks][4];   // the two half-waves hold sums over different source rows of the same targets
+    R far[kColBlocks][NM];   // the two half-waves hold sums over different source rows of the same targets
 #pragma unroll
     for (int cb = 0; cb < kColBlocks; cb++)
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
+      for (int k = 0; k < NM; k++) {
         const R half_sum = acc[cb][k][0] + acc[cb][k][1];
         far[cb][k] = half_sum + __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(half_sum)));
         acc[cb][k] = f32x2{0, 0};
@@ -639,15 +773,14 @@ template <class KER, int CB> __device__ __forceinline__ void centered_mfma_stoke
     for (int q = 0; q < NQ; q++) {
       const int64_t t = tbase + (NQ * he + q) * 32 + me;
       const int64_t tc = (t < a.Nt) ? t : a.Nt - 1;
-      R out[K1];
+      R xtp[3], mine[NM], out[K1];
 #pragma unroll
-      for (int k = 0; k < 3; k++) {
-        const R xtp = a.xt[tc * 3 + k] - c[k];   // x_t' (re-read: an L2 hit per flush instead of 12 registers for the whole kernel)
-        const R sk = he ? far[NQ + q][k] : far[q][k], scn = he ? far[NQ + q][3] : far[q][3];
-        out[k] = fma_(xtp, scn, sk);
-      }
-      if constexpr (K1 == 4) out[3] = he ? far[NQ + q][3] : far[q][3];
+      for (int k = 0; k < 3; k++) xtp[k] = a.xt[tc * 3 + k] - c[k];   // x_t' (re-read: an L2 hit per flush instead of 12 registers for the whole kernel)
+#pragma unroll
+      for (int k = 0; k < NM; k++) mine[k] = he ? far[NQ + q][k] : far[q][k];
+      MP::finish(out, mine, xtp);
       if (last) {
+        finish_acc<Ker, R, 0>(accn[q]);     // (what the exact pair leaves for the end: the traction kernel's lower triangle)
 #pragma unroll
         for (int k = 0; k < K1; k++) out[k] += accn[q][k];
       }
@@ -674,15 +807,15 @@ template <class KER, int CB> __device__ __forceinline__ void centered_mfma_stoke
     carry = n - nrows;
     if (nrows > 0 && lane < carry) {   // the leftovers to the front (one wave: its LDS operations complete in program order)
       u32x4 w[RW - 1];
-      float sv[6];
+      float sv[NSC];
 #pragma unroll
       for (int i = 0; i < RW - 1; i++) w[i] = farA[(nrows + lane) * RW + i];
 #pragma unroll
-      for (int k = 0; k < 6; k++) sv[k] = farS[k * kRowsCap + nrows + lane];
+      for (int k = 0; k < NSC; k++) sv[k] = farS[k * kRowsCap + nrows + lane];
 #pragma unroll
       for (int i = 0; i < RW - 1; i++) farA[lane * RW + i] = w[i];
 #pragma unroll
-      for (int k = 0; k < 6; k++) farS[k * kRowsCap + lane] = sv[k];
+      for (int k = 0; k < NSC; k++) farS[k * kRowsCap + lane] = sv[k];
     }
     if ((it & (kFlushTiles - 1)) == kFlushTiles - 1 && it + 1 < ntile) emit(false);
   }
@@ -699,8 +832,8 @@ template <class KER, int CB> __device__ __forceinline__ void centered_mfma_stoke
   for (int cb = 0; cb < kColBlocks; cb++) asm volatile("" ::"v"(Bop[cb][0]), "v"(Bop[cb][1]));   // (as the Laplace kernels: every MFMA operand outlives the VALU work behind it)
   emit(true);
 }
-template <class KER> __global__ void __launch_bounds__(kWaveBlock) centered_mfma_stokeslet_f32_kernel(const EvalArgs<float> a) {
-  centered_mfma_stokeslet_f32_body<KER, 4>(a);
+template <class MP> __global__ void __launch_bounds__(kWaveBlock) centered_mfma_moments_f32_kernel(const EvalArgs<float> a) {
+  centered_mfma_moments_f32_body<MP, 4>(a);
 }
 
 // The kernels.  Single layer: 256 targets per wave with one column block's MFMAs ahead = 168 registers = three waves per SIMD (asked of the compiler: left to

@@ -169,7 +169,8 @@ def test_one_process_multi_device_slabs_follow_the_morton_curve(O):
     assert rel_l2(three32[sel].astype(np.float64), ref) <= 1e-4
 
 
-@pytest.mark.parametrize("name,dt", [("Laplace3D-FxdU", np.float64), ("Stokes3D-FxUP", np.float64), ("Stokes3D-FxU", np.float32), ("Stokes3D-FxUP", np.float32)])
+@pytest.mark.parametrize("name,dt", [("Laplace3D-FxdU", np.float64), ("Stokes3D-FxUP", np.float64), ("Stokes3D-FxU", np.float32), ("Stokes3D-FxUP", np.float32),
+                                     ("Stokes3D-DxU", np.float32), ("Stokes3D-FxT", np.float32)])
 def test_vector_kernels_through_the_operator_handle_and_slabs(O, name, dt):
     """Kernels with several outputs per target on the tile-centred path (fp64: far moments on the vector pipe; fp32 Stokeslet family: the matrix-core kernel)
     through the entries that keep the targets in Morton order: the operator handle on one device (no per-call sort: the kernel writes K1 values per target in
@@ -179,16 +180,17 @@ def test_vector_kernels_through_the_operator_handle_and_slabs(O, name, dt):
     info = sctl_amd.kernel_info(name)
     k1 = info["k1"]
     xt, xs, f = rng.random(n * 3).astype(dt), rng.random(ns * 3).astype(dt), (rng.random(ns * info["k0"]) - 0.5).astype(dt)
+    xn = (rng.random(ns * 3) - 0.5).astype(dt) if info["nd"] else None
     f64 = dt == np.float64
     assert sctl_amd.plan(name, 0 if f64 else 1, n, ns)["path"] == "tile-centred"
-    one = sctl_amd.eval_host(name, xt, xs, None, f)
+    one = sctl_amd.eval_host(name, xt, xs, xn, f)
     sel = rng.choice(n, 200, replace=False)
-    ref = O.eval(name, xt.reshape(n, 3)[sel].astype(np.float64).ravel().copy(), xs.astype(np.float64), None, f.astype(np.float64))
+    ref = O.eval(name, xt.reshape(n, 3)[sel].astype(np.float64).ravel().copy(), xs.astype(np.float64), None if xn is None else xn.astype(np.float64), f.astype(np.float64))
     assert rel_l2(one.reshape(n, k1)[sel].ravel(), ref) <= (1e-12 if f64 else 2e-5)
     for devs in ((0,), (0, 0, 0)):
         op = sctl_amd.DirectOp(name, dt, devices=devs)
         op.set_targets(xt)
-        op.set_sources(xs)
+        op.set_sources(xs, xn)
         u = np.full(n * k1, 0.25, dtype=dt)
         op.eval(f, u, accumulate=True)
         assert rel_l2(u - dt(0.25), one) <= (1e-13 if f64 else 2e-5), (devs, rel_l2(u - dt(0.25), one))     # (slabs have their own cluster centres: fp32 sums differ in the last bits)
@@ -231,10 +233,11 @@ def test_centred_fp32_contractions_on_the_matrix_cores_match_the_packed_valu_ker
 
 
 @pytest.mark.parametrize("kind", ["uniform", "clustered", "surface", "identical_targets", "offset"])
-@pytest.mark.parametrize("name", ["Stokes3D-FxU", "Stokes3D-FSxU", "Stokes3D-FxUP"])
+@pytest.mark.parametrize("name", ["Stokes3D-FxU", "Stokes3D-FSxU", "Stokes3D-FxUP", "Stokes3D-DxU", "Stokes3D-FxT"])
 def test_fp32_stokeslet_family_on_the_matrix_cores(O, name, kind):
-    """fp32 Stokeslet, Stokeslet + source/sink and velocity + pressure (kernel_functions.hpp:74-95, 148-198) at the default accuracy: r^2 AND (x_t - x_s).f of the far
-    pairs as split-bf16 contractions on the matrix cores, four far moments per target on the vector pipe (centered_mfma_kernel.hpp, round 4) — against the exact fp32
+    """fp32 Stokeslet, Stokeslet + source/sink, velocity + pressure, the stresslet and the traction tensor (kernel_functions.hpp:74-198) at the default accuracy: r^2 AND the dot
+    products (x_t - x_s).f, (x_t - x_s).n of the far pairs as split-bf16 contractions on the matrix cores, four far moments per target on the vector pipe
+    (centered_mfma_kernel.hpp, round 4) — against the exact fp32
     kernel and the fp64 oracle on the same fp32-rounded inputs, on the clouds that stress the far / near split, ragged sizes; accumulate semantics; more digits than the
     seed's take the exact kernel; six evaluations bit-identical."""
     import torch
@@ -243,28 +246,30 @@ def test_fp32_stokeslet_family_on_the_matrix_cores(O, name, kind):
     xt, xs = np.ascontiguousarray(xt.ravel()).astype(np.float32), np.ascontiguousarray(xs.ravel()).astype(np.float32)
     info = sctl_amd.kernel_info(name)
     f = (rng.random(NS * info["k0"]) - 0.5).astype(np.float32)
+    xn = (rng.random(NS * 3) - 0.5).astype(np.float32) if info["nd"] else None
     pl = sctl_amd.plan(name, 1, NT, NS)
     assert pl["path"] == "tile-centred" and pl["pipe"].startswith("bf16 matrix cores") and pl["trg_per_lane"] == 2, pl
     assert sctl_amd.plan(name, 1, NT, NS, digits=9)["path"] == "exact"                      # fp32 beyond the seed's accuracy: the exact kernel's Newton step
     assert sctl_amd.plan(name, 0, NT, NS)["pipe"] == "vector pipe"
     d = [torch.from_numpy(a).cuda() for a in (xt, xs, f)]
-    runs = [sctl_amd.eval_device(name, d[0], d[1], None, d[2]).clone() for _ in range(6)]
+    dn = None if xn is None else torch.from_numpy(xn).cuda()
+    runs = [sctl_amd.eval_device(name, d[0], d[1], dn, d[2]).clone() for _ in range(6)]
     for r in runs[1:]:
         assert int((r.view(torch.int32) != runs[0].view(torch.int32)).sum()) == 0, (name, kind)
     u = runs[0].cpu().numpy()
     assert np.all(np.isfinite(u))
     v0 = torch.from_numpy((rng.random(NT * info["k1"]) - 0.5).astype(np.float32)).cuda()
-    u_acc = sctl_amd.eval_device(name, d[0], d[1], None, d[2], v_trg=v0.clone()).cpu().numpy()        # v_trg += (generic-kernel.txx:184)
+    u_acc = sctl_amd.eval_device(name, d[0], d[1], dn, d[2], v_trg=v0.clone()).cpu().numpy()          # v_trg += (generic-kernel.txx:184)
     assert np.max(np.abs((u_acc - v0.cpu().numpy()) - u)) <= 1e-5 * np.max(np.abs(u))
     for env in ("SCTL_AMD_MFMA_F32", "SCTL_AMD_CENTERED"):                                              # either switch leaves the exact fp32 kernel
         os.environ[env] = "0"
         try:
             assert sctl_amd.plan(name, 1, NT, NS)["path"] == "exact"
-            u_exact = sctl_amd.eval_device(name, d[0], d[1], None, d[2]).cpu().numpy()
+            u_exact = sctl_amd.eval_device(name, d[0], d[1], dn, d[2]).cpu().numpy()
         finally:
             del os.environ[env]
     sel = rng.choice(NT, 300, replace=False)
-    ref = O.eval(name, xt.reshape(NT, 3)[sel].astype(np.float64).ravel().copy(), xs.astype(np.float64), None, f.astype(np.float64))
+    ref = O.eval(name, xt.reshape(NT, 3)[sel].astype(np.float64).ravel().copy(), xs.astype(np.float64), None if xn is None else xn.astype(np.float64), f.astype(np.float64))
     e_m, e_x = rel_l2(u.reshape(NT, -1)[sel].ravel(), ref), rel_l2(u_exact.reshape(NT, -1)[sel].ravel(), ref)
     # the split-bf16 r^2 (good to ~3e-7 after the far condition's cancellation) enters the 1/r^3 terms three times: 1.5e-6 .. 4e-6 where the exact kernel has 5e-7
     assert e_m <= 2e-5 and e_m <= 10 * e_x + 2e-6, (name, kind, e_m, e_x)
@@ -315,7 +320,8 @@ def test_centred_kernels_give_bit_identical_results_run_to_run(kind):
 
 
 _CENTRED_FORMS = [("Laplace3D-FxU", np.float64), ("Laplace3D-FxU", np.float32), ("Laplace3D-DxU", np.float64), ("Laplace3D-DxU", np.float32), ("Laplace3D-FxdU", np.float64),
-                  ("Stokes3D-FxUP", np.float64), ("Stokes3D-FxU", np.float32), ("Stokes3D-FSxU", np.float32), ("Stokes3D-FxUP", np.float32)]
+                  ("Stokes3D-FxUP", np.float64), ("Stokes3D-FxU", np.float32), ("Stokes3D-FSxU", np.float32), ("Stokes3D-FxUP", np.float32), ("Stokes3D-DxU", np.float32),
+                  ("Stokes3D-FxT", np.float32)]
 
 
 @pytest.mark.parametrize("seed", range(6))
