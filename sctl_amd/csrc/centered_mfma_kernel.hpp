@@ -504,7 +504,8 @@ template <class MP, int CB> __device__ __forceinline__ void centered_mfma_moment
   constexpr int kColBlocks = CB, NQ = CB / 2, K0 = Ker::K0, K1 = Ker::K1, ND = Ker::ND, NNUM = MP::NNUM, NSC = MP::NSC, NM = MP::NM;
   using V = Rec4<R>::V;
   constexpr int NEARW = (Ker::NREC + 3) / 4;
-  constexpr int RW = MP::PREBUILT ? 4 * (1 + NNUM) + 1 : 4 + NNUM + 1;   // the r2 row, the numerators (rows, or four coefficients each), one word of padding
+  constexpr int NDATA = MP::PREBUILT ? 4 * (1 + NNUM) : 4 + NNUM;   // 16-byte words of a far row: the r2 row, the numerators (rows, or four coefficients each)
+  constexpr int RW = NDATA | 1;                                     // row stride: odd, so that the 32 rows a half-wave reads together spread over all banks
   constexpr int kRowsCap = kWaveTile + kMfmaRows, kRows4 = kRowsCap / 4;
   constexpr int kNear = 64;                     // pending near sources (three words each; with 128 the workgroup's LDS would leave one wave per SIMD)
   __shared__ u32x4 farA[kRowsCap * RW];
@@ -745,7 +746,7 @@ template <class MP, int CB> __device__ __forceinline__ void centered_mfma_moment
     row[0] = row[1] = row[2] = u32x4{0, 0, 0, 0};
     row[3] = a_tail(1.0f, true);
 #pragma unroll
-    for (int i = 4; i < RW - 1; i++) row[i] = u32x4{0, 0, 0, 0};
+    for (int i = 4; i < NDATA; i++) row[i] = u32x4{0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < NSC; k++) farS[k * kRowsCap + q] = 0;
   };
@@ -806,14 +807,14 @@ template <class MP, int CB> __device__ __forceinline__ void centered_mfma_moment
     run_far(nrows);
     carry = n - nrows;
     if (nrows > 0 && lane < carry) {   // the leftovers to the front (one wave: its LDS operations complete in program order)
-      u32x4 w[RW - 1];
+      u32x4 w[NDATA];
       float sv[NSC];
 #pragma unroll
-      for (int i = 0; i < RW - 1; i++) w[i] = farA[(nrows + lane) * RW + i];
+      for (int i = 0; i < NDATA; i++) w[i] = farA[(nrows + lane) * RW + i];
 #pragma unroll
       for (int k = 0; k < NSC; k++) sv[k] = farS[k * kRowsCap + nrows + lane];
 #pragma unroll
-      for (int i = 0; i < RW - 1; i++) farA[lane * RW + i] = w[i];
+      for (int i = 0; i < NDATA; i++) farA[lane * RW + i] = w[i];
 #pragma unroll
       for (int k = 0; k < NSC; k++) farS[k * kRowsCap + lane] = sv[k];
     }
