@@ -1,6 +1,6 @@
 """One-off extended randomised parity run (not part of the test suite: ~5 minutes of GPU + host oracle time): list evaluation with random
 kernels / precisions / digits / ragged lists (tiny, mid and large target ranges, so every item kind of lists_kernel.hpp runs), the all-pairs
-entries at random sizes, and the fused far + near potential on random operators over 1-3 slabs.  Every result against the CPU oracle.
+entries at random sizes, every tile-centred form forced onto small ragged problems, and the fused far + near potential on random operators over 1-3 slabs.  Every result against the CPU oracle.
     python tools/fuzz_extended.py [cases per family, default 150]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -90,6 +90,41 @@ for c in range(n_cases):                                   # ---- all pairs, hos
     tol = (1e-12 if digits < 0 or digits >= 15 else 10.0 * 10.0 ** -digits) if dt == np.float64 else (1e-4 if digits == 5 else 3e-5)
     note("all-pairs", rel(u.reshape(Nt, -1)[sel], ref), tol, (c, name, dt.__name__, digits, Nt, Ns))
 print("all-pairs: %d cases, worst err/tol %.3f  (%.0f s)" % (n_cases, worst.get("all-pairs", 0), time.time() - t0), flush=True)
+
+t0 = time.time()
+FORMS = [("Laplace3D-FxU", np.float64), ("Laplace3D-FxU", np.float32), ("Laplace3D-DxU", np.float64), ("Laplace3D-DxU", np.float32), ("Laplace3D-FxdU", np.float64),
+         ("Stokes3D-FxUP", np.float64), ("Stokes3D-FxU", np.float32), ("Stokes3D-FSxU", np.float32), ("Stokes3D-FxUP", np.float32), ("Stokes3D-DxU", np.float32), ("Stokes3D-FxT", np.float32)]
+os.environ["SCTL_AMD_CENTERED"] = "1"                      # ---- every tile-centred form forced onto small ragged problems (>= 128 targets, >= 64 sources)
+for c in range(n_cases):
+    rng = np.random.default_rng(80000 + c)
+    name, dt = FORMS[int(rng.integers(0, len(FORMS)))]
+    info = sctl_amd.kernel_info(name)
+    f64 = dt == np.float64
+    digits = int(rng.choice([-1, -1, 12, 9, 5])) if (f64 or name.startswith("Laplace")) else int(rng.choice([-1, -1, 5]))
+    Nt, Ns = int(rng.integers(128, 6000)), int(rng.integers(64, 6000))
+    scale = float(rng.choice([1.0, 1e-2, 1e2]))
+    xs = (scale * rng.random(Ns * 3)).astype(dt)
+    kind = int(rng.integers(0, 3))
+    xt = (scale * (rng.random(Nt * 3) if kind == 0 else 0.1 * rng.random(Nt * 3) + 0.45 if kind == 1 else np.repeat(rng.random((max(1, Nt // 50), 3)), 50, axis=0)[:Nt].ravel() if Nt >= 50 else rng.random(Nt * 3))).astype(dt)
+    if xt.size != Nt * 3:
+        xt = (scale * rng.random(Nt * 3)).astype(dt)
+    if rng.random() < 0.4:
+        k = min(Nt, Ns, int(rng.integers(1, 300)))
+        xt[:k * 3] = xs[:k * 3]
+    xn, f = (rng.random(Ns * info["nd"]) - 0.5).astype(dt), (rng.random(Ns * info["k0"]) - 0.5).astype(dt)
+    assert sctl_amd.plan(name, 0 if f64 else 1, Nt, Ns, digits=digits)["path"] == "tile-centred", (name, dt.__name__, digits)
+    if rng.random() < 0.5:
+        u = sctl_amd.eval_host(name, xt, xs, xn, f, digits=digits, devices=[0] * int(rng.integers(1, 4)))
+    else:
+        op = sctl_amd.DirectOp(name, dt, devices=[0] * int(rng.integers(1, 4)))
+        op.set_targets(xt); op.set_sources(xs, xn)
+        u = op.eval(f, digits=digits)
+        op.close()
+    ref = O.eval(name, xt.astype(np.float64), xs.astype(np.float64), xn.astype(np.float64), f.astype(np.float64))
+    tol = (1e-12 if digits < 0 or digits >= 15 else 10.0 * 10.0 ** -digits) if f64 else (1e-4 if digits == 5 else 3e-5)
+    note("forced tile-centred", rel(u, ref), tol, (c, name, dt.__name__, digits, Nt, Ns, kind, scale))
+del os.environ["SCTL_AMD_CENTERED"]
+print("forced tile-centred: %d cases, worst err/tol %.3f  (%.0f s)" % (n_cases, worst.get("forced tile-centred", 0), time.time() - t0), flush=True)
 
 t0 = time.time()
 for c in range(max(1, n_cases // 5)):                       # ---- fused far + near potential on random operators
