@@ -66,6 +66,50 @@ __device__ __forceinline__ u32x4 b_tail(float tt) {
   return u32x4{kOnes2, hi2(1.0f, tt), hi2(r1, r2), 0u};
 }
 
+// which (target tile, source split) this workgroup takes: XCD k owns the splits [k gridDim.y / 8, (k + 1) gridDim.y / 8) for all tiles (centered_kernel.hpp)
+__device__ __forceinline__ void centered_tile_and_split(unsigned& tile_idx, unsigned& split_idx) {
+  tile_idx = blockIdx.x; split_idx = blockIdx.y;
+  if ((gridDim.y & 7u) == 0) {
+    const unsigned b = blockIdx.y * gridDim.x + blockIdx.x, xcd = b & 7u, j = b >> 3, per = gridDim.y >> 3;
+    tile_idx = j % gridDim.x;
+    split_idx = xcd * per + j / gridDim.x;
+  }
+}
+// The targets of a wave as B operands: lane (m, h) holds, for each of the CB column blocks, column m's slice (K entries 16 step + 8 h + 0..7) of the contraction against
+// -2 x_t' and |x_t'|^2; c = the cluster's centre (bounding-box midpoint, wave-uniform), the return value the largest |x_t'|^2 of the wave.
+template <int CB> __device__ __forceinline__ float centered_mfma_targets(const EvalArgs<float>& a, int64_t tbase, int m, int h, float (&c)[3], u32x4 (&Bop)[CB][2]) {
+  using R = float;
+  R xb[CB][3];
+  R lo[3] = {max_finite<R>(), max_finite<R>(), max_finite<R>()}, hi[3] = {-lo[0], -lo[0], -lo[0]};
+#pragma unroll
+  for (int cb = 0; cb < CB; cb++) {
+    int64_t t = tbase + cb * 32 + m;
+    if (t >= a.Nt) t = a.Nt - 1;   // tail lanes repeat the last target; never stored
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      xb[cb][k] = a.xt[t * 3 + k];
+      lo[k] = (xb[cb][k] < lo[k]) ? xb[cb][k] : lo[k];
+      hi[k] = (xb[cb][k] > hi[k]) ? xb[cb][k] : hi[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) c[k] = uniform_(R(0.5) * wave_min(lo[k]) + R(0.5) * wave_max(hi[k]));
+  R rt2 = 0;
+#pragma unroll
+  for (int cb = 0; cb < CB; cb++) {
+    const R p[3] = {xb[cb][0] - c[0], xb[cb][1] - c[1], xb[cb][2] - c[2]};
+    const R tt = len2(p);
+    rt2 = (tt > rt2) ? tt : rt2;
+    const u32x4 w[4] = {b_word(-2.0f * p[0]), b_word(-2.0f * p[1]), b_word(-2.0f * p[2]), b_tail(tt)};   // (-2 x exactly: a power of two)
+#pragma unroll
+    for (int step = 0; step < 2; step++) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) Bop[cb][step][i] = h ? w[2 * step + 1][i] : w[2 * step][i];
+    }
+  }
+  return uniform_(wave_max(rt2));
+}
+
 // a.xt: Morton-sorted targets; a.v_trg / a.partial indexed like a.xt (as centered_kernel)
 // CB: column blocks of 32 targets per wave (4: 128 targets, as the VALU kernel with two targets per lane; 8: 256).  STEP: keep ONE column block's MFMAs
 // ahead of the VALU work, no more (two sets of results in registers instead of one per block)
@@ -84,48 +128,15 @@ template <bool DL, int CB, bool STEP> __device__ __forceinline__ void centered_m
   float* const farF = (float*)farF4;
 
   const int lane = threadIdx.x, m = lane & 31, h = lane >> 5;
-  unsigned tile_idx = blockIdx.x, split_idx = blockIdx.y;
-  if ((gridDim.y & 7u) == 0) {   // XCD k owns the splits [k gridDim.y / 8, (k + 1) gridDim.y / 8) for all tiles (centered_kernel.hpp)
-    const unsigned b = blockIdx.y * gridDim.x + blockIdx.x, xcd = b & 7u, j = b >> 3, per = gridDim.y >> 3;
-    tile_idx = j % gridDim.x;
-    split_idx = xcd * per + j / gridDim.x;
-  }
+  unsigned tile_idx, split_idx;
+  centered_tile_and_split(tile_idx, split_idx);
   const int64_t tbase = (int64_t)tile_idx * (32 * CB);
   const typename Ker::template Consts<R> K(nullptr);
 
-  // ---- this lane's four B-operand targets (column m of each block), cluster centre and radius ------------------------
-  R xb[kColBlocks][3], c[3];
-  {
-    R lo[3] = {max_finite<R>(), max_finite<R>(), max_finite<R>()}, hi[3] = {-lo[0], -lo[0], -lo[0]};
-#pragma unroll
-    for (int cb = 0; cb < kColBlocks; cb++) {
-      int64_t t = tbase + cb * 32 + m;
-      if (t >= a.Nt) t = a.Nt - 1;   // tail lanes repeat the last target; never stored
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-        xb[cb][k] = a.xt[t * 3 + k];
-        lo[k] = (xb[cb][k] < lo[k]) ? xb[cb][k] : lo[k];
-        hi[k] = (xb[cb][k] > hi[k]) ? xb[cb][k] : hi[k];
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < 3; k++) c[k] = uniform_(R(0.5) * wave_min(lo[k]) + R(0.5) * wave_max(hi[k]));
-  }
+  // ---- this lane's B-operand targets (column m of each block), cluster centre and radius ------------------------
+  R c[3];
   u32x4 Bop[kColBlocks][2];   // this lane's slice (K entries 16 step + 8 h + 0..7) of its targets' columns
-  R rt2 = 0;
-#pragma unroll
-  for (int cb = 0; cb < kColBlocks; cb++) {
-    const R p[3] = {xb[cb][0] - c[0], xb[cb][1] - c[1], xb[cb][2] - c[2]};
-    const R tt = len2(p);
-    rt2 = (tt > rt2) ? tt : rt2;
-    const u32x4 w[4] = {b_word(-2.0f * p[0]), b_word(-2.0f * p[1]), b_word(-2.0f * p[2]), b_tail(tt)};   // (-2 x exactly: a power of two)
-#pragma unroll
-    for (int step = 0; step < 2; step++) {
-#pragma unroll
-      for (int i = 0; i < 4; i++) Bop[cb][step][i] = h ? w[2 * step + 1][i] : w[2 * step][i];
-    }
-  }
-  rt2 = uniform_(wave_max(rt2));
+  const R rt2 = centered_mfma_targets<kColBlocks>(a, tbase, m, h, c, Bop);
   const R near_r2 = R(a.ctx.v[0]) * rt2;   // NaN coordinates fail every comparison => "near" => exact path
 
   R acc[kColBlocks];   // far sums of this half-wave's source rows, per column block
@@ -514,48 +525,14 @@ template <class MP, int CB> __device__ __forceinline__ void centered_mfma_moment
   float* const farS = (float*)farS4;
 
   const int lane = threadIdx.x, m = lane & 31, h = lane >> 5;
-  unsigned tile_idx = blockIdx.x, split_idx = blockIdx.y;
-  if ((gridDim.y & 7u) == 0) {   // XCD k owns the splits [k gridDim.y / 8, (k + 1) gridDim.y / 8) for all tiles (centered_kernel.hpp)
-    const unsigned b = blockIdx.y * gridDim.x + blockIdx.x, xcd = b & 7u, j = b >> 3, per = gridDim.y >> 3;
-    tile_idx = j % gridDim.x;
-    split_idx = xcd * per + j / gridDim.x;
-  }
+  unsigned tile_idx, split_idx;
+  centered_tile_and_split(tile_idx, split_idx);
   const int64_t tbase = (int64_t)tile_idx * (32 * CB);
   const typename Ker::template Consts<R> K(nullptr);
 
   R c[3];
   u32x4 Bop[kColBlocks][2];
-  R rt2 = 0;
-  {
-    R xb[kColBlocks][3];
-    R lo[3] = {max_finite<R>(), max_finite<R>(), max_finite<R>()}, hi[3] = {-lo[0], -lo[0], -lo[0]};
-#pragma unroll
-    for (int cb = 0; cb < kColBlocks; cb++) {
-      int64_t t = tbase + cb * 32 + m;
-      if (t >= a.Nt) t = a.Nt - 1;
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-        xb[cb][k] = a.xt[t * 3 + k];
-        lo[k] = (xb[cb][k] < lo[k]) ? xb[cb][k] : lo[k];
-        hi[k] = (xb[cb][k] > hi[k]) ? xb[cb][k] : hi[k];
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < 3; k++) c[k] = uniform_(R(0.5) * wave_min(lo[k]) + R(0.5) * wave_max(hi[k]));
-#pragma unroll
-    for (int cb = 0; cb < kColBlocks; cb++) {
-      const R p[3] = {xb[cb][0] - c[0], xb[cb][1] - c[1], xb[cb][2] - c[2]};
-      const R tt = len2(p);
-      rt2 = (tt > rt2) ? tt : rt2;
-      const u32x4 w[4] = {b_word(-2.0f * p[0]), b_word(-2.0f * p[1]), b_word(-2.0f * p[2]), b_tail(tt)};
-#pragma unroll
-      for (int step = 0; step < 2; step++) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) Bop[cb][step][i] = h ? w[2 * step + 1][i] : w[2 * step][i];
-      }
-    }
-  }
-  rt2 = uniform_(wave_max(rt2));
+  const R rt2 = centered_mfma_targets<kColBlocks>(a, tbase, m, h, c, Bop);
   const R near_r2 = R(a.ctx.v[0]) * rt2;
 
   f32x2 acc[kColBlocks][NM];   // the far moments of this half-wave's source rows, per column block: {even rows, odd rows}
