@@ -321,6 +321,16 @@ template <class R, class KER> struct CenteredStokeslet : ExtraWords<R, 8> {
 // extra moment sum y^3 c — and with the near pairs, a 12-real near record and six LDS words per far source it measured 2.5 .. 3.7 % SLOWER than the exact kernel at
 // 2^18 and 2^20: profiles/r04_ab_centered_vec.txt.)
 
+// Which (target tile, source split) a workgroup of the tile-centred kernels takes: see the comment in centered_kernel below (XCD k owns the splits
+// [k gridDim.y / 8, (k + 1) gridDim.y / 8) for all tiles).
+__device__ __forceinline__ void centered_tile_and_split(unsigned& tile_idx, unsigned& split_idx) {
+  tile_idx = blockIdx.x; split_idx = blockIdx.y;
+  if ((gridDim.y & 7u) == 0) {
+    const unsigned b = blockIdx.y * gridDim.x + blockIdx.x, xcd = b & 7u, j = b >> 3, per = gridDim.y >> 3;
+    tile_idx = j % gridDim.x;
+    split_idx = xcd * per + j / gridDim.x;
+  }
+}
 // a.xt: Morton-sorted targets; a.v_trg / a.partial: indexed like a.xt (the caller scatters back).
 // (asking the compiler for 5-6 waves/SIMD instead of the 4 its registers allow, or unrolling the far loop by 2 or 8 instead of 4, costs 0-3 %:
 // profiles/r03_ab_centered_occupancy.txt)
@@ -347,12 +357,8 @@ __global__ void __launch_bounds__(kWaveBlock) centered_kernel(const EvalArgs<R> 
   // source split — 8 x the source data through the fabric —; when the splits divide by 8, XCD k instead owns the splits
   // [k * gridDim.y / 8, (k + 1) * gridDim.y / 8) for ALL tiles: one split (2 MB at 2^20 sources / 16) stays in its 4 MB L2 while the
   // tiles stream by.  Same work per XCD; the results do not depend on the mapping.
-  unsigned tile_idx = blockIdx.x, split_idx = blockIdx.y;
-  if ((gridDim.y & 7u) == 0) {   // (A/B against the plain mapping: profiles/r02_ab_xcd_map.txt)
-    const unsigned b = blockIdx.y * gridDim.x + blockIdx.x, xcd = b & 7u, j = b >> 3, per = gridDim.y >> 3;
-    tile_idx = j % gridDim.x;
-    split_idx = xcd * per + j / gridDim.x;
-  }
+  unsigned tile_idx, split_idx;
+  centered_tile_and_split(tile_idx, split_idx);   // (A/B against the plain mapping: profiles/r02_ab_xcd_map.txt)
   const int64_t tbase = (int64_t)tile_idx * (kWaveBlock * T);
   const typename Ker::template Consts<R> K(nullptr);
 

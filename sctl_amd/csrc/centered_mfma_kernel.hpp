@@ -66,15 +66,6 @@ __device__ __forceinline__ u32x4 b_tail(float tt) {
   return u32x4{kOnes2, hi2(1.0f, tt), hi2(r1, r2), 0u};
 }
 
-// which (target tile, source split) this workgroup takes: XCD k owns the splits [k gridDim.y / 8, (k + 1) gridDim.y / 8) for all tiles (centered_kernel.hpp)
-__device__ __forceinline__ void centered_tile_and_split(unsigned& tile_idx, unsigned& split_idx) {
-  tile_idx = blockIdx.x; split_idx = blockIdx.y;
-  if ((gridDim.y & 7u) == 0) {
-    const unsigned b = blockIdx.y * gridDim.x + blockIdx.x, xcd = b & 7u, j = b >> 3, per = gridDim.y >> 3;
-    tile_idx = j % gridDim.x;
-    split_idx = xcd * per + j / gridDim.x;
-  }
-}
 // The targets of a wave as B operands: lane (m, h) holds, for each of the CB column blocks, column m's slice (K entries 16 step + 8 h + 0..7) of the contraction against
 // -2 x_t' and |x_t'|^2; c = the cluster's centre (bounding-box midpoint, wave-uniform), the return value the largest |x_t'|^2 of the wave.
 template <int CB> __device__ __forceinline__ float centered_mfma_targets(const EvalArgs<float>& a, int64_t tbase, int m, int h, float (&c)[3], u32x4 (&Bop)[CB][2]) {
