@@ -453,6 +453,30 @@ struct MfmaStresslet {
     for (int k = 0; k < 3; k++) out[k] = fma_(xtp[k], far[3], far[k]);
   }
 };
+// the gradient of the Laplace single layer (Laplace3D_FxdU, kernel_functions.hpp:53-72): u_j = sum_s f r_j / r^3 = x_t'_j S_0 - S_j with A = f y^3, S_0 = sum A, S_j = sum A x_s'_j.
+// No dot product: the "numerator" is the density itself, handed to every pair of its row as a contraction of {0, 0, 0, f} against the ones.
+struct MfmaGradient {
+  using Ker = Laplace3D_FxdU;
+  static constexpr int NNUM = 1, NSC = 3, NM = 4;
+  static constexpr bool PREBUILT = false, AHEAD = true;
+  static __device__ __forceinline__ void numerators(float (&num)[NNUM][4], const float (&)[3], const float*, const float* f) {
+    num[0][0] = 0; num[0][1] = 0; num[0][2] = 0; num[0][3] = f[0];
+  }
+  static __device__ __forceinline__ void scalars(float (&sc)[NSC], const float (&p)[3], const float*, const float*) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) sc[k] = p[k];
+  }
+  static __device__ __forceinline__ void pairs(f32x2 (&acc)[NM], f32x2 y, const f32x2 (&dn)[NNUM], const f32x2 (&s)[NSC]) {
+    const f32x2 cc = dn[0] * (y * y * y);
+    acc[3] += cc;
+#pragma unroll
+    for (int j = 0; j < 3; j++) acc[j] -= cc * s[j];
+  }
+  static __device__ __forceinline__ void finish(float (&out)[3], const float (&far)[NM], const float (&xtp)[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) out[k] = fma_(xtp[k], far[3], far[k]);
+  }
+};
 // the traction tensor (Stokes3D_FxT, kernel_functions.hpp:122-146): u_jk = sum_s (r.f) r_j r_k / r^5.  With c = (r.f) y^5 and r = x_t' - x_s':
 // u_jk = x_t'_j x_t'_k S_c - x_t'_j S_k - S_j x_t'_k + S_jk, S_c = sum c, S_j = sum c x_s'_j, S_jk = sum c x_s'_j x_s'_k (six of them): ten moments, the products
 // c x_s'_j made once per pair and used for S_j and S_jk — 17 packed instructions per two pairs where the exact pair has 2 x 21.

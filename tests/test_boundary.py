@@ -100,7 +100,7 @@ def test_launch_planner():
         assert sctl_amd.plan("Laplace3D-DxU", 0, 1 << 20, 1 << 20)["path"] == "tile-centred"  # scalar Laplace kernels have a centred form
         grad = sctl_amd.plan("Laplace3D-FxdU", 0, 1 << 20, 1 << 20)                           # the gradient: far sources as moments (round 4), three targets per lane, fp64 only
         assert grad["path"] == "tile-centred" and grad["trg_per_lane"] == 3 and grad["workspace_bytes"] == grad["src_splits"] * 3 * 8 << 20
-        assert sctl_amd.plan("Laplace3D-FxdU", 1, 1 << 20, 1 << 20)["path"] == "exact"
+        assert sctl_amd.plan("Laplace3D-FxdU", 1, 1 << 20, 1 << 20, digits=9)["path"] == "exact"   # (fp32 at the seed's accuracy: the matrix-core moments kernel, below)
         up = sctl_amd.plan("Stokes3D-FxUP", 0, 1 << 20, 1 << 20)                              # velocity + pressure: the pressure IS one of the Stokeslet's four far moments
         assert up["path"] == "tile-centred" and up["trg_per_lane"] == 4 and up["workspace_bytes"] == up["src_splits"] * 4 * 8 << 20
         for name in ("Stokes3D-FxU", "Stokes3D-FSxU"):                                        # ... for the Stokeslet itself the moments save one instruction of 21: not taken
@@ -113,9 +113,9 @@ def test_launch_planner():
                 assert sctl_amd.plan(name, 1, 1 << 20, 1 << 20, digits=9)["pipe"] == "vector pipe"
                 assert sctl_amd.plan(name, 0, 1 << 20, 1 << 20)["pipe"] == "vector pipe"
         assert small["pipe"] == "vector pipe" and sctl_amd.plan("Laplace3D-FDxUdU", 1, 1 << 20, 1 << 20)["pipe"] == "vector pipe"
-        # ... and for the fp32 Stokeslet family and stresslet (round 4: r.f, r.n are further contractions against the same targets' operand), at the seed's accuracy only
+        # ... and for six fp32 kernels with several outputs per target (round 4: r.f, r.n are further contractions against the same targets' operand), at the seed's accuracy only
         if os.environ.get("SCTL_AMD_MFMA_F32") != "0":
-            for name in ("Stokes3D-FxU", "Stokes3D-FSxU", "Stokes3D-FxUP", "Stokes3D-DxU", "Stokes3D-FxT"):
+            for name in ("Stokes3D-FxU", "Stokes3D-FSxU", "Stokes3D-FxUP", "Stokes3D-DxU", "Stokes3D-FxT", "Laplace3D-FxdU"):
                 p32 = sctl_amd.plan(name, 1, 1 << 20, 1 << 20)
                 assert p32["path"] == "tile-centred" and p32["pipe"].startswith("bf16 matrix cores") and p32["trg_per_lane"] == 2, p32
                 p9 = sctl_amd.plan(name, 1, 1 << 20, 1 << 20, digits=9)
@@ -203,7 +203,7 @@ def test_device_assembly_of_the_matrix_core_kernels_keeps_mfma_operands_untouche
     registers within 24 instructions of its issue (a precaution the compiler does not take by itself: DESIGN.md §4.2a)."""
     r = subprocess.run([os.sys.executable, os.path.join(ROOT, "tools", "check_mfma_operands.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert r.stdout.count("v_mfma, 0 operand write(s)") == 9, r.stdout      # the nine matrix-core kernels (Laplace: two 256-target forms, two 128-target ones; the Stokeslet family's three, stresslet, traction) were found and are clean
+    assert r.stdout.count("v_mfma, 0 operand write(s)") == 10, r.stdout     # the ten matrix-core kernels (Laplace: two 256-target forms, two 128-target ones; the moments kernel's six policies) were found and are clean
 
 
 def test_device_assembly_of_every_shipped_kernel_keeps_the_isa_rules():
