@@ -312,13 +312,13 @@ int sctl_amd_eval_plan(int kernel, int real, int64_t Nt, int64_t Ns, int64_t Nt_
 /* Which device algorithm sctl_amd_eval_device/_host will use for a problem at the DEFAULT accuracy: 0 = the exact all-pairs kernel
  * (d = x_t - x_s per pair, as generic-kernel.txx:83), 1 = the tile-centred path (targets Morton-sorted on the device, far sources through
  * r2 = |x_t'|^2 + |x_s'|^2 - 2 x_t'.x_s', near sources exact): Laplace3D-FxU/-DxU (f64, f32), Laplace3D-FxdU and
- * Stokes3D-FxUP (f64), Stokes3D-FxU/-FSxU/-FxUP/-DxU/-FxT and Laplace3D-FxdU (f32, at the seed's accuracy only: sctl_amd_eval_pipe answers for a given `digits`).
+ * Stokes3D-FxUP (f64), Stokes3D-FxU/-FSxU/-FxUP/-DxU/-FxT and Laplace3D-FxdU/-FDxUdU (f32, at the seed's accuracy only: sctl_amd_eval_pipe answers for a given `digits`).
  * Negative = error code.  Setting SCTL_AMD_CENTERED=0 in the environment forces 0. */
 int sctl_amd_eval_path(int kernel, int real, int64_t Nt, int64_t Ns, int64_t Nt_whole);
 
 /* Which execution units the far pairs of that problem run on at `digits` (for roofline labels; no side effects): 0 = the vector pipe, exact kernel;
  * 1 = the vector pipe, tile-centred path; 2 = tile-centred path with r2 (and the double layer's / the Stokeslet's dot product) as split-bf16 contractions on
- * the MATRIX cores (v_mfma_f32_32x32x16_bf16) and v_rsq_f32 + the accumulation on the vector pipe — fp32 Laplace3D-FxU/-DxU, -FxdU and five fp32 Stokes kernels at
+ * the MATRIX cores (v_mfma_f32_32x32x16_bf16) and v_rsq_f32 + the accumulation on the vector pipe — fp32 Laplace3D-FxU/-DxU/-FxdU/-FDxUdU and five fp32 Stokes kernels at
  * the seed's accuracy (digits < 8); SCTL_AMD_MFMA_F32=0 in the environment keeps Laplace3D-FxU/-DxU on 1 and the others on 0.  Negative = error
  * code.  (The reference has one pipe, the host's SIMD units: vec.hpp.) */
 int sctl_amd_eval_pipe(int kernel, int real, int64_t Nt, int64_t Ns, int64_t Nt_whole, int digits);

@@ -226,7 +226,7 @@ bool has_centered_path(const KernelEntry& k, int real, int mode = -1) {
   if (k.id == SCTL_AMD_LAPLACE3D_FXU || k.id == SCTL_AMD_LAPLACE3D_DXU) return true;
   if (real == SCTL_AMD_F64) return k.id == SCTL_AMD_LAPLACE3D_FXDU || k.id == SCTL_AMD_STOKES3D_FXUP;
   // fp32: the Stokeslet family and the stresslet at the seed's accuracy, r2 and the dot products on the matrix cores (centered_mfma_kernel.hpp); more digits: the exact kernel
-  return (k.id == SCTL_AMD_STOKES3D_FXU || k.id == SCTL_AMD_STOKES3D_FSXU || k.id == SCTL_AMD_STOKES3D_FXUP || k.id == SCTL_AMD_STOKES3D_DXU || k.id == SCTL_AMD_STOKES3D_FXT || k.id == SCTL_AMD_LAPLACE3D_FXDU) && centered_pipe(k.id, real, mode) == 2;
+  return (k.id == SCTL_AMD_STOKES3D_FXU || k.id == SCTL_AMD_STOKES3D_FSXU || k.id == SCTL_AMD_STOKES3D_FXUP || k.id == SCTL_AMD_STOKES3D_DXU || k.id == SCTL_AMD_STOKES3D_FXT || k.id == SCTL_AMD_LAPLACE3D_FXDU || k.id == SCTL_AMD_LAPLACE3D_FDXUDU) && centered_pipe(k.id, real, mode) == 2;
 }
 constexpr int64_t kPresortMinTargets = 1 << 17;   // sctl_amd_op_* keeps the targets of such kernels in Morton order from this size on
 

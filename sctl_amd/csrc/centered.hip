@@ -36,7 +36,7 @@ bool use_mfma_f32() {
 // (what sctl_amd_eval_pipe reports; must say what launch_centered does)
 int centered_pipe(int kernel_id, int real, int mode) {
   const bool has = kernel_id == Laplace3D_FxU::ID || kernel_id == Laplace3D_DxU::ID || kernel_id == Stokes3D_FxU::ID || kernel_id == Stokes3D_FSxU::ID ||
-                   kernel_id == Stokes3D_FxUP::ID || kernel_id == Stokes3D_DxU::ID || kernel_id == Stokes3D_FxT::ID || kernel_id == Laplace3D_FxdU::ID;   // (Stokeslet family and stresslet, round 4: r.f, r.n are further contractions, as the double layer's numerator)
+                   kernel_id == Stokes3D_FxUP::ID || kernel_id == Stokes3D_DxU::ID || kernel_id == Stokes3D_FxT::ID || kernel_id == Laplace3D_FxdU::ID || kernel_id == Laplace3D_FDxUdU::ID;   // (Stokeslet family and stresslet, round 4: r.f, r.n are further contractions, as the double layer's numerator)
   return (has && real == 1 /* SCTL_AMD_F32 */ && mode == 0 && use_mfma_f32()) ? 2 : 1;
 }
 // Targets per wave (= per workgroup) of that path: 64 per target of a lane on the vector pipe (the policy's targets_per_lane); for the matrix-core kernels 256 = eight
@@ -65,6 +65,8 @@ template <class CP> struct mfma_moments_policy { using type = void; };
 template <class KER> struct mfma_moments_policy<CenteredStokeslet<float, KER>> { using type = MfmaStokeslet<KER>; };
 template <> struct mfma_moments_policy<CenteredStresslet<float>> { using type = MfmaStresslet; };
 template <class R> struct CenteredTraction { using Ker = Stokes3D_FxT; };
+template <class R> struct CenteredFusedLaplace { using Ker = Laplace3D_FDxUdU; };
+template <> struct mfma_moments_policy<CenteredFusedLaplace<float>> { using type = MfmaFusedLaplace; };
 template <> struct mfma_moments_policy<CenteredFxdU<float>> { using type = MfmaGradient; };
 template <> struct mfma_moments_policy<CenteredTraction<float>> { using type = MfmaTraction; };
 template <class CP, class R, int MODE> void launch_centered(const EvalArgs<R>& a, dim3 grid, int per_wave, hipStream_t st) {
@@ -226,6 +228,7 @@ hipError_t eval_centered(int kernel_id, int64_t Nt, int64_t Ns, const R* xt, con
   }
   if constexpr (std::is_same<R, float>::value) {    // fp32 kernels with several outputs per target on the matrix cores (mode 0; capi.hip: has_centered_path)
     if (kernel_id == Laplace3D_FxdU::ID) return eval_centered_t<CenteredFxdU<R>, R>(Nt, Ns, xt, xs, xn, f, v_trg, scale, mode, cus, st, presorted, density);
+    if (kernel_id == Laplace3D_FDxUdU::ID) return eval_centered_t<CenteredFusedLaplace<R>, R>(Nt, Ns, xt, xs, xn, f, v_trg, scale, mode, cus, st, presorted, density);
     if (kernel_id == Stokes3D_FxU::ID) return eval_centered_t<CenteredStokeslet<R, Stokes3D_FxU>, R>(Nt, Ns, xt, xs, xn, f, v_trg, scale, mode, cus, st, presorted, density);
     if (kernel_id == Stokes3D_FSxU::ID) return eval_centered_t<CenteredStokeslet<R, Stokes3D_FSxU>, R>(Nt, Ns, xt, xs, xn, f, v_trg, scale, mode, cus, st, presorted, density);
     if (kernel_id == Stokes3D_FxUP::ID) return eval_centered_t<CenteredStokeslet<R, Stokes3D_FxUP>, R>(Nt, Ns, xt, xs, xn, f, v_trg, scale, mode, cus, st, presorted, density);

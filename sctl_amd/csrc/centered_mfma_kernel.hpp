@@ -403,7 +403,7 @@ template <class KER> struct MfmaStokeslet {
   using Ker = KER;
   static_assert((KER::K0 == 3 || KER::K0 == 4) && (KER::K1 == 3 || KER::K1 == 4) && KER::ND == 0, "the Stokeslet family");
   static constexpr int NNUM = 1, NSC = 6, NM = 4;
-  static constexpr bool PREBUILT = true, AHEAD = false;   // (252 registers: none left to keep a column block's contractions ahead)
+  static constexpr bool PREBUILT = true, AHEAD = false, SCALARS_ONCE = true;   // (252 registers: none left to keep a column block's contractions ahead)
   static __device__ __forceinline__ void numerators(float (&num)[NNUM][4], const float (&p)[3], const float*, const float* f) {
     float g3 = -(p[0] * f[0] + p[1] * f[1] + p[2] * f[2]);
     if constexpr (KER::K0 == 4) g3 += f[3];
@@ -432,7 +432,7 @@ template <class KER> struct MfmaStokeslet {
 struct MfmaStresslet {
   using Ker = Stokes3D_DxU;
   static constexpr int NNUM = 2, NSC = 3, NM = 4;
-  static constexpr bool PREBUILT = false, AHEAD = true;   // (three prebuilt rows per source would be 20 KB of LDS per wave: three waves per TWO SIMDs)
+  static constexpr bool PREBUILT = false, AHEAD = true, SCALARS_ONCE = true;   // (three prebuilt rows per source would be 20 KB of LDS per wave: three waves per TWO SIMDs)
   static __device__ __forceinline__ void numerators(float (&num)[NNUM][4], const float (&p)[3], const float* n, const float* f) {
     num[0][0] = -0.5f * f[0]; num[0][1] = -0.5f * f[1]; num[0][2] = -0.5f * f[2]; num[0][3] = -(p[0] * f[0] + p[1] * f[1] + p[2] * f[2]);
     num[1][0] = -0.5f * n[0]; num[1][1] = -0.5f * n[1]; num[1][2] = -0.5f * n[2]; num[1][3] = -(p[0] * n[0] + p[1] * n[1] + p[2] * n[2]);
@@ -458,7 +458,7 @@ struct MfmaStresslet {
 struct MfmaGradient {
   using Ker = Laplace3D_FxdU;
   static constexpr int NNUM = 1, NSC = 3, NM = 4;
-  static constexpr bool PREBUILT = false, AHEAD = true;
+  static constexpr bool PREBUILT = false, AHEAD = true, SCALARS_ONCE = true;
   static __device__ __forceinline__ void numerators(float (&num)[NNUM][4], const float (&)[3], const float*, const float* f) {
     num[0][0] = 0; num[0][1] = 0; num[0][2] = 0; num[0][3] = f[0];
   }
@@ -477,13 +477,48 @@ struct MfmaGradient {
     for (int k = 0; k < 3; k++) out[k] = fma_(xtp[k], far[3], far[k]);
   }
 };
+// the fused Laplace single + double layer kernel, potential and gradient (Laplace3D_FDxUdU, ukernels.hpp; BASELINE config 2's functor): with m = mu n, w = r.m,
+// u = sum q y + w y^3 and grad_j u = sum m_j y^3 - a r_j, a = q y^3 + 3 w y^5: moments P = sum (q y + w y^3), G_j = sum (m_j y^3 + a x_s'_j), A = sum a;
+// grad_j = G_j - x_t'_j A.  Two contractions beside r2: r.m, and the charge q as a broadcast row.
+struct MfmaFusedLaplace {
+  using Ker = Laplace3D_FDxUdU;
+  static constexpr int NNUM = 2, NSC = 6, NM = 5;
+  static constexpr bool PREBUILT = false, AHEAD = false, SCALARS_ONCE = false;   // (all 96 row scalars in registers: 291 VGPRs, one wave per SIMD, level with the exact kernel)
+  static __device__ __forceinline__ void numerators(float (&num)[NNUM][4], const float (&p)[3], const float* n, const float* f) {
+    const float m[3] = {n[0] * f[1], n[1] * f[1], n[2] * f[1]};
+    num[0][0] = -0.5f * m[0]; num[0][1] = -0.5f * m[1]; num[0][2] = -0.5f * m[2]; num[0][3] = -(p[0] * m[0] + p[1] * m[1] + p[2] * m[2]);
+    num[1][0] = 0; num[1][1] = 0; num[1][2] = 0; num[1][3] = f[0];
+  }
+  static __device__ __forceinline__ void scalars(float (&sc)[NSC], const float (&p)[3], const float* n, const float* f) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) { sc[k] = n[k] * f[1]; sc[3 + k] = p[k]; }
+  }
+  static __device__ __forceinline__ void pairs(f32x2 (&acc)[NM], f32x2 y, const f32x2 (&dn)[NNUM], const f32x2 (&s)[NSC]) {
+    const f32x2 y2 = y * y, y3 = y2 * y;
+    const f32x2 w3 = dn[0] * y3;
+    acc[0] += dn[1] * y;
+    acc[0] += w3;
+    const f32x2 a = f32x2{3.0f, 3.0f} * (w3 * y2) + dn[1] * y3;
+    acc[4] += a;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      acc[1 + j] += s[j] * y3;
+      acc[1 + j] += a * s[3 + j];
+    }
+  }
+  static __device__ __forceinline__ void finish(float (&out)[4], const float (&far)[NM], const float (&xtp)[3]) {
+    out[0] = far[0];
+#pragma unroll
+    for (int k = 0; k < 3; k++) out[1 + k] = fma_(-xtp[k], far[4], far[1 + k]);
+  }
+};
 // the traction tensor (Stokes3D_FxT, kernel_functions.hpp:122-146): u_jk = sum_s (r.f) r_j r_k / r^5.  With c = (r.f) y^5 and r = x_t' - x_s':
 // u_jk = x_t'_j x_t'_k S_c - x_t'_j S_k - S_j x_t'_k + S_jk, S_c = sum c, S_j = sum c x_s'_j, S_jk = sum c x_s'_j x_s'_k (six of them): ten moments, the products
 // c x_s'_j made once per pair and used for S_j and S_jk — 17 packed instructions per two pairs where the exact pair has 2 x 21.
 struct MfmaTraction {
   using Ker = Stokes3D_FxT;
   static constexpr int NNUM = 1, NSC = 3, NM = 10;
-  static constexpr bool PREBUILT = false, AHEAD = false;
+  static constexpr bool PREBUILT = false, AHEAD = false, SCALARS_ONCE = true;
   static __device__ __forceinline__ void numerators(float (&num)[NNUM][4], const float (&p)[3], const float*, const float* f) {
     num[0][0] = -0.5f * f[0]; num[0][1] = -0.5f * f[1]; num[0][2] = -0.5f * f[2]; num[0][3] = -(p[0] * f[0] + p[1] * f[1] + p[2] * f[2]);
   }
@@ -696,11 +731,16 @@ template <class MP, int CB> __device__ __forceinline__ void centered_mfma_moment
         for (int n = 0; n < NNUM; n++) numerator_words(__builtin_bit_cast(f32x4, row[4 + n]), lr >> 5, G0[n], G1[n]);
       }
       const f32x4* const sc = sc0 + (r0 >> 2);
-      f32x4 w[NSC][4];   // the scalars of this lane's sixteen rows 8 k + 4 h + {0..3}: read once per row block, used by every column block
+      // the scalars of this lane's sixteen rows 8 k + 4 h + {0..3}: read once per row block and used by every column block — or, for a policy whose registers
+      // do not hold all of them beside two waves per SIMD (MP::SCALARS_ONCE false), re-read for every column block, eight rows at a time
+      constexpr int WK = MP::SCALARS_ONCE ? 4 : 2;
+      f32x4 w[NSC][WK];
+      if constexpr (MP::SCALARS_ONCE) {
 #pragma unroll
-      for (int comp = 0; comp < NSC; comp++)
+        for (int comp = 0; comp < NSC; comp++)
 #pragma unroll
-        for (int k = 0; k < 4; k++) w[comp][k] = sc[comp * kRows4 + 2 * k];
+          for (int k = 0; k < 4; k++) w[comp][k] = sc[comp * kRows4 + 2 * k];
+      }
       f32x16 r2 = mfma(A1, Bop[0][1], mfma(A0, Bop[0][0], zero));
 #pragma unroll
       for (int cb = 0; cb < kColBlocks; cb++) {
@@ -715,14 +755,24 @@ template <class MP, int CB> __device__ __forceinline__ void centered_mfma_moment
         for (int v = 0; v < 16; v++) r2[v] = __builtin_amdgcn_rsqf(r2[v]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int v = 0; v < 16; v += 2) {
-          const int k = v >> 2, e = v & 3;
-          f32x2 dn[NNUM], s[NSC];
+        for (int half = 0; half < 2; half++) {
+          if constexpr (!MP::SCALARS_ONCE) {
 #pragma unroll
-          for (int n = 0; n < NNUM; n++) dn[n] = f32x2{rn[n][v], rn[n][v + 1]};
+            for (int comp = 0; comp < NSC; comp++)
 #pragma unroll
-          for (int j = 0; j < NSC; j++) s[j] = f32x2{w[j][k][e], w[j][k][e + 1]};
-          MP::pairs(acc[cb], f32x2{r2[v], r2[v + 1]}, dn, s);
+              for (int k = 0; k < 2; k++) w[comp][k] = sc[comp * kRows4 + 2 * (2 * half + k)];
+          }
+#pragma unroll
+          for (int v8 = 0; v8 < 8; v8 += 2) {
+            const int v = 8 * half + v8, k = MP::SCALARS_ONCE ? (v >> 2) : (v8 >> 2), e = v & 3;
+            f32x2 dn[NNUM], s[NSC];
+#pragma unroll
+            for (int n = 0; n < NNUM; n++) dn[n] = f32x2{rn[n][v], rn[n][v + 1]};
+#pragma unroll
+            for (int j = 0; j < NSC; j++) s[j] = f32x2{w[j][k][e], w[j][k][e + 1]};
+            MP::pairs(acc[cb], f32x2{r2[v], r2[v + 1]}, dn, s);
+          }
+          if constexpr (!MP::SCALARS_ONCE) __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (MP::AHEAD) r2 = r2n;

@@ -81,7 +81,7 @@ def test_launch_planner():
                 k1 = sctl_amd.kernel_info(name)["k1"]
                 assert p["workspace_bytes"] == (0 if p["src_splits"] == 1 else p["src_splits"] * N * k1 * (8 if real == 0 else 4))
     # the exact kernel from 2^34 pairs on: a split's source data <= 2 MB, splits in eights (one share per XCD), <= 64 splits, <= 4 GB of partial sums
-    for name, real, logn in (("Stokes3D-FxU", 0, 20), ("Stokes3D-FxU", 0, 18), ("Laplace3D-FDxUdU", 0, 20), ("Helmholtz3D-FxU", 0, 20), ("Laplace3D-FDxUdU", 1, 23),
+    for name, real, logn in (("Stokes3D-FxU", 0, 20), ("Stokes3D-FxU", 0, 18), ("Laplace3D-FDxUdU", 0, 20), ("Helmholtz3D-FxU", 0, 20), ("Helmholtz3D-FxU", 1, 23),
                              ("Laplace3D-FxdU", 0, 17)):
         p, i = sctl_amd.plan(name, real, 1 << logn, 1 << logn), sctl_amd.kernel_info(name)
         rs = 8 if real == 0 else 4
@@ -112,10 +112,10 @@ def test_launch_planner():
                 assert sctl_amd.plan(name, 1, 1 << 20, 1 << 20)["pipe"].startswith("bf16 matrix cores")
                 assert sctl_amd.plan(name, 1, 1 << 20, 1 << 20, digits=9)["pipe"] == "vector pipe"
                 assert sctl_amd.plan(name, 0, 1 << 20, 1 << 20)["pipe"] == "vector pipe"
-        assert small["pipe"] == "vector pipe" and sctl_amd.plan("Laplace3D-FDxUdU", 1, 1 << 20, 1 << 20)["pipe"] == "vector pipe"
-        # ... and for six fp32 kernels with several outputs per target (round 4: r.f, r.n are further contractions against the same targets' operand), at the seed's accuracy only
+        assert small["pipe"] == "vector pipe" and sctl_amd.plan("Helmholtz3D-FxU", 1, 1 << 20, 1 << 20)["pipe"] == "vector pipe"
+        # ... and for seven fp32 kernels with several outputs per target (round 4: r.f, r.n are further contractions against the same targets' operand), at the seed's accuracy only
         if os.environ.get("SCTL_AMD_MFMA_F32") != "0":
-            for name in ("Stokes3D-FxU", "Stokes3D-FSxU", "Stokes3D-FxUP", "Stokes3D-DxU", "Stokes3D-FxT", "Laplace3D-FxdU"):
+            for name in ("Stokes3D-FxU", "Stokes3D-FSxU", "Stokes3D-FxUP", "Stokes3D-DxU", "Stokes3D-FxT", "Laplace3D-FxdU", "Laplace3D-FDxUdU"):
                 p32 = sctl_amd.plan(name, 1, 1 << 20, 1 << 20)
                 assert p32["path"] == "tile-centred" and p32["pipe"].startswith("bf16 matrix cores") and p32["trg_per_lane"] == 2, p32
                 p9 = sctl_amd.plan(name, 1, 1 << 20, 1 << 20, digits=9)
@@ -203,7 +203,7 @@ def test_device_assembly_of_the_matrix_core_kernels_keeps_mfma_operands_untouche
     registers within 24 instructions of its issue (a precaution the compiler does not take by itself: DESIGN.md §4.2a)."""
     r = subprocess.run([os.sys.executable, os.path.join(ROOT, "tools", "check_mfma_operands.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert r.stdout.count("v_mfma, 0 operand write(s)") == 10, r.stdout     # the ten matrix-core kernels (Laplace: two 256-target forms, two 128-target ones; the moments kernel's six policies) were found and are clean
+    assert r.stdout.count("v_mfma, 0 operand write(s)") == 11, r.stdout     # the eleven matrix-core kernels (Laplace: two 256-target forms, two 128-target ones; the moments kernel's seven policies) were found and are clean
 
 
 def test_device_assembly_of_every_shipped_kernel_keeps_the_isa_rules():

@@ -170,7 +170,7 @@ def test_one_process_multi_device_slabs_follow_the_morton_curve(O):
 
 
 @pytest.mark.parametrize("name,dt", [("Laplace3D-FxdU", np.float64), ("Stokes3D-FxUP", np.float64), ("Stokes3D-FxU", np.float32), ("Stokes3D-FxUP", np.float32),
-                                     ("Stokes3D-DxU", np.float32), ("Stokes3D-FxT", np.float32), ("Laplace3D-FxdU", np.float32)])
+                                     ("Stokes3D-DxU", np.float32), ("Stokes3D-FxT", np.float32), ("Laplace3D-FxdU", np.float32), ("Laplace3D-FDxUdU", np.float32)])
 def test_vector_kernels_through_the_operator_handle_and_slabs(O, name, dt):
     """Kernels with several outputs per target on the tile-centred path (fp64: far moments on the vector pipe; fp32 Stokeslet family: the matrix-core kernel)
     through the entries that keep the targets in Morton order: the operator handle on one device (no per-call sort: the kernel writes K1 values per target in
@@ -233,9 +233,9 @@ def test_centred_fp32_contractions_on_the_matrix_cores_match_the_packed_valu_ker
 
 
 @pytest.mark.parametrize("kind", ["uniform", "clustered", "surface", "identical_targets", "offset"])
-@pytest.mark.parametrize("name", ["Stokes3D-FxU", "Stokes3D-FSxU", "Stokes3D-FxUP", "Stokes3D-DxU", "Stokes3D-FxT", "Laplace3D-FxdU"])
+@pytest.mark.parametrize("name", ["Stokes3D-FxU", "Stokes3D-FSxU", "Stokes3D-FxUP", "Stokes3D-DxU", "Stokes3D-FxT", "Laplace3D-FxdU", "Laplace3D-FDxUdU"])
 def test_fp32_vector_kernels_on_the_matrix_cores(O, name, kind):
-    """fp32 Stokeslet, Stokeslet + source/sink, velocity + pressure, the stresslet, the traction tensor and the Laplace gradient (kernel_functions.hpp:53-198) at the default accuracy: r^2 AND the dot
+    """fp32 Stokeslet, Stokeslet + source/sink, velocity + pressure, the stresslet, the traction tensor, the Laplace gradient (kernel_functions.hpp:53-198) and the fused Laplace kernel at the default accuracy: r^2 AND the dot
     products (x_t - x_s).f, (x_t - x_s).n of the far pairs as split-bf16 contractions on the matrix cores, four far moments per target on the vector pipe
     (centered_mfma_kernel.hpp, round 4) — against the exact fp32
     kernel and the fp64 oracle on the same fp32-rounded inputs, on the clouds that stress the far / near split, ragged sizes; accumulate semantics; more digits than the
@@ -321,7 +321,7 @@ def test_centred_kernels_give_bit_identical_results_run_to_run(kind):
 
 _CENTRED_FORMS = [("Laplace3D-FxU", np.float64), ("Laplace3D-FxU", np.float32), ("Laplace3D-DxU", np.float64), ("Laplace3D-DxU", np.float32), ("Laplace3D-FxdU", np.float64),
                   ("Stokes3D-FxUP", np.float64), ("Stokes3D-FxU", np.float32), ("Stokes3D-FSxU", np.float32), ("Stokes3D-FxUP", np.float32), ("Stokes3D-DxU", np.float32),
-                  ("Stokes3D-FxT", np.float32), ("Laplace3D-FxdU", np.float32)]
+                  ("Stokes3D-FxT", np.float32), ("Laplace3D-FxdU", np.float32), ("Laplace3D-FDxUdU", np.float32)]
 
 
 @pytest.mark.parametrize("seed", range(6))

@@ -30,5 +30,5 @@ def run(name, N, reps):
     print("%-14s fp32 N=2^%d  %s/%s T=%d %d splits %9.2f ms (%5.1f %%) err %.1e finite %s repeat-identical %s | exact %9.2f ms (%5.1f %%) err %.1e  -> x%.2f" % (
         name, N.bit_length()-1, a[2]['path'], a[2]['pipe'][:12], a[2]['trg_per_lane'], a[2]['src_splits'], a[0], 100*N*N*fl/(a[0]*1e-3)/157.3e12, a[1], a[4], a[3],
         b[0], 100*N*N*fl/(b[0]*1e-3)/157.3e12, b[1], b[0]/a[0]), flush=True)
-for name in (sys.argv[1:] or ['Stokes3D-FxU', 'Stokes3D-FSxU', 'Stokes3D-FxUP', 'Stokes3D-DxU', 'Stokes3D-FxT', 'Laplace3D-FxdU']):
+for name in (sys.argv[1:] or ['Stokes3D-FxU', 'Stokes3D-FSxU', 'Stokes3D-FxUP', 'Stokes3D-DxU', 'Stokes3D-FxT', 'Laplace3D-FxdU', 'Laplace3D-FDxUdU']):
     run(name, 1 << 18, 5); run(name, 1 << 20, 2)

@@ -93,7 +93,7 @@ print("all-pairs: %d cases, worst err/tol %.3f  (%.0f s)" % (n_cases, worst.get(
 
 t0 = time.time()
 FORMS = [("Laplace3D-FxU", np.float64), ("Laplace3D-FxU", np.float32), ("Laplace3D-DxU", np.float64), ("Laplace3D-DxU", np.float32), ("Laplace3D-FxdU", np.float64),
-         ("Stokes3D-FxUP", np.float64), ("Stokes3D-FxU", np.float32), ("Stokes3D-FSxU", np.float32), ("Stokes3D-FxUP", np.float32), ("Stokes3D-DxU", np.float32), ("Stokes3D-FxT", np.float32), ("Laplace3D-FxdU", np.float32)]
+         ("Stokes3D-FxUP", np.float64), ("Stokes3D-FxU", np.float32), ("Stokes3D-FSxU", np.float32), ("Stokes3D-FxUP", np.float32), ("Stokes3D-DxU", np.float32), ("Stokes3D-FxT", np.float32), ("Laplace3D-FxdU", np.float32), ("Laplace3D-FDxUdU", np.float32)]
 os.environ["SCTL_AMD_CENTERED"] = "1"                      # ---- every tile-centred form forced onto small ragged problems (>= 128 targets, >= 64 sources)
 for c in range(n_cases):
     rng = np.random.default_rng(80000 + c)
