@@ -95,7 +95,7 @@ template <class CP, class R, int MODE> void launch_centered(const EvalArgs<R>& a
 // v_trg[Nt] += scale * sum_s (kernel of the policy CP), mode = rsqrt refinement (ukernels.hpp)
 // Launch geometry of the centred kernel: one wave per workgroup, 64*T targets each.  The kernel holds 103 VGPRs, so 16
 // waves are resident per CU; the work per wave varies with its share of near sources (0.5 % .. 34 % at 2^20 uniform
-// points), so the source range is split until there are >= 32 "rounds" of workgroups — measured on 2^20 x 2^20:
+// points), so the source range is split until there are >= 64 "rounds" of workgroups (counted at 128 targets per wave) — measured on 2^20 x 2^20:
 // 1 split 517 ms, 4 splits 480 ms, 16 splits 469 ms (exact kernel on the same GPU: 520 ms).
 // Second rule (round 2): a split's source data (src_bytes per source: coordinates, density, normals as the kernel reads them) should fit the
 // 4 MB L2 of the XCD that owns the split (centered_kernel.hpp), i.e. <= 2 MB: at 2^23 fp32 sources in 2 splits every wave streamed 64 MB per
@@ -103,14 +103,16 @@ template <class CP, class R, int MODE> void launch_centered(const EvalArgs<R>& a
 void centered_plan(int64_t Nt, int64_t Ns, int cus, int src_bytes, int* T, int* splits, int64_t* chunk) {
   *T = 2;   // (the split rule was sized for 128 targets per wave; one target per lane measured 498 ms against 465 ms at 2^20, round 1)
   const int64_t wg_x = (Nt + kWaveBlock * 2 - 1) / (kWaveBlock * 2);
-  const int64_t want = (int64_t)cus * 16 * 32;
+  const int64_t want = (int64_t)cus * 16 * 64;   // (x 32 until round 4: 2^20 x 2^20 in 32 instead of 16 splits — workgroups half as long, a shorter last round — 402.8 -> 398.5 ms,
+                                                 //  at 10 digits 373.4 -> 369.7; 64 splits the same again: profiles/r04_ab_rank_splits.txt)
   const int64_t ntile = (Ns + kWaveTile - 1) / kWaveTile;
   int64_t s = (want + wg_x - 1) / wg_x;
   const int64_t s_l2 = (Ns * src_bytes + (2 << 20) - 1) / (2 << 20);
   if (s < s_l2) s = s_l2;
   if (s > ntile / 64) s = ntile / 64;      // at least 64 tiles (4096 sources) per split
   if (s > 8) s = (s + 7) & ~(int64_t)7;    // the XCD-aware mapping needs a multiple of 8
-  if (s > 64) s = 64;
+  if (s > 256) s = 256;                    // (64 until round 4: a rank's slab of 2^17 targets then ran 8 rounds of 6 ms workgroups and lost 4 % to the last one — 51.7 -> 50.1 ms with 128 splits,
+                                           //  95.5 -> 98.5 % of an eighth of the whole problem: profiles/r04_ab_rank_splits.txt)
   if (s < 1) s = 1;
   const int64_t tiles_per = (ntile + s - 1) / s;
   *chunk = tiles_per * kWaveTile;

@@ -95,7 +95,7 @@ def test_launch_planner():
     assert small["src_splits"] == 16 and small["path"] == "exact"
     if os.environ.get("SCTL_AMD_CENTERED") != "0":      # the headline problem takes the tile-centred Laplace path: one wave per workgroup
         head = sctl_amd.plan("Laplace3D-FxU", 0, 1 << 20, 1 << 20)
-        assert head["path"] == "tile-centred" and head["src_splits"] == 16 and head["workgroups"] == 4096 * 16 and head["trg_per_lane"] == 4   # 256 targets per wave (fp64)
+        assert head["path"] == "tile-centred" and head["src_splits"] == 32 and head["workgroups"] == 4096 * 32 and head["trg_per_lane"] == 4   # 256 targets per wave (fp64)
         assert sctl_amd.plan("Laplace3D-FxU", 1, 1 << 20, 1 << 20)["path"] == "tile-centred"
         assert sctl_amd.plan("Laplace3D-DxU", 0, 1 << 20, 1 << 20)["path"] == "tile-centred"  # scalar Laplace kernels have a centred form
         grad = sctl_amd.plan("Laplace3D-FxdU", 0, 1 << 20, 1 << 20)                           # the gradient: far sources as moments (round 4), three targets per lane, fp64 only
