@@ -26,7 +26,7 @@ int comm_gather_to_device(sctl_amd_comm* c, const void* local, int64_t nbytes, v
 template <class R>
 hipError_t eval_centered(int kernel_id, int64_t Nt, int64_t Ns, const R* xt, const R* xs, const R* xn, const R* f, R* v_trg, double scale, int mode,
                          int cus, hipStream_t st, bool presorted, int64_t density);
-void centered_plan(int64_t Nt, int64_t Ns, int cus, int src_bytes, int* T, int* splits, int64_t* chunk);
+void centered_plan(int64_t Nt, int64_t Ns, int cus, int src_bytes, int out_bytes, int* T, int* splits, int64_t* chunk);
 int centered_pipe(int kernel_id, int real, int mode);
 int centered_targets_per_wave(int kernel_id, int real, int mode, int64_t density);
 hipError_t morton_order_device(int real, const void* d_x, int64_t n, void* d_sorted, uint32_t* d_perm, hipStream_t st);   // centered.hip
@@ -1283,7 +1283,7 @@ int sctl_amd_eval_plan(int kernel, int real, int64_t Nt, int64_t Ns, int64_t Nt_
   if (use_centered(*k, real, Nt, Ns, Nt_whole, false, mode_for(real, digits))) {
     int T, splits;
     int64_t chunk;
-    centered_plan(Nt, Ns, cu_count(), (real == SCTL_AMD_F64 ? 8 : 4) * (3 + k->nd + k->k0), &T, &splits, &chunk);
+    centered_plan(Nt, Ns, cu_count(), (real == SCTL_AMD_F64 ? 8 : 4) * (3 + k->nd + k->k0), (real == SCTL_AMD_F64 ? 8 : 4) * k->k1, &T, &splits, &chunk);
     const int64_t per_wave = centered_targets_per_wave(k->id, real, mode_for(real, digits), Nt > Nt_whole ? Nt : Nt_whole);   // (centered.hip)
     (void)T;
     if (trg_per_lane) *trg_per_lane = (int)(per_wave / 64);

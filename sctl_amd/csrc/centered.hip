@@ -100,7 +100,7 @@ template <class CP, class R, int MODE> void launch_centered(const EvalArgs<R>& a
 // Second rule (round 2): a split's source data (src_bytes per source: coordinates, density, normals as the kernel reads them) should fit the
 // 4 MB L2 of the XCD that owns the split (centered_kernel.hpp), i.e. <= 2 MB: at 2^23 fp32 sources in 2 splits every wave streamed 64 MB per
 // split through a 4 MB cache and the launch pulled 3.66 TB through the fabric (13 600 x the algorithmic bytes; PMC, profiles/r02_laplace_sl_f32_*).
-void centered_plan(int64_t Nt, int64_t Ns, int cus, int src_bytes, int* T, int* splits, int64_t* chunk) {
+void centered_plan(int64_t Nt, int64_t Ns, int cus, int src_bytes, int out_bytes, int* T, int* splits, int64_t* chunk) {
   *T = 2;   // (the split rule was sized for 128 targets per wave; one target per lane measured 498 ms against 465 ms at 2^20, round 1)
   const int64_t wg_x = (Nt + kWaveBlock * 2 - 1) / (kWaveBlock * 2);
   const int64_t want = (int64_t)cus * 16 * 64;   // (x 32 until round 4: 2^20 x 2^20 in 32 instead of 16 splits — workgroups half as long, a shorter last round — 402.8 -> 398.5 ms,
@@ -113,6 +113,10 @@ void centered_plan(int64_t Nt, int64_t Ns, int cus, int src_bytes, int* T, int* 
   if (s > 8) s = (s + 7) & ~(int64_t)7;    // the XCD-aware mapping needs a multiple of 8
   if (s > 256) s = 256;                    // (64 until round 4: a rank's slab of 2^17 targets then ran 8 rounds of 6 ms workgroups and lost 4 % to the last one — 51.7 -> 50.1 ms with 128 splits,
                                            //  95.5 -> 98.5 % of an eighth of the whole problem: profiles/r04_ab_rank_splits.txt)
+  {   // ... and at most 2 GB of partial sums (out_bytes per target and split), in eights while that leaves any
+    const int64_t fit = ((int64_t)2 << 30) / (Nt * out_bytes > 0 ? Nt * out_bytes : 1);
+    if (s > fit) s = (fit >= 8) ? (fit & ~(int64_t)7) : fit;
+  }
   if (s < 1) s = 1;
   const int64_t tiles_per = (ntile + s - 1) / s;
   *chunk = tiles_per * kWaveTile;
@@ -126,7 +130,7 @@ hipError_t eval_centered_t(int64_t Nt, int64_t Ns, const R* xt, const R* xs, con
   constexpr int K1 = CP::Ker::K1;
   int T, splits;
   int64_t chunk;
-  centered_plan(Nt, Ns, cus, (int)sizeof(R) * (3 + CP::Ker::ND + CP::Ker::K0), &T, &splits, &chunk);
+  centered_plan(Nt, Ns, cus, (int)sizeof(R) * (3 + CP::Ker::ND + CP::Ker::K0), (int)sizeof(R) * K1, &T, &splits, &chunk);
   if (presorted) {   // the caller keeps the targets in Morton order (sctl_amd_op_*): no sort, no gather, results in place
     R* partial = nullptr;
     if (splits > 1) {
